@@ -1,0 +1,158 @@
+/* libmfcc_hip -- C ABI of the MI355X (gfx950) MFCC engine.
+ *
+ * The reference (jvargeaux/speech_to_text) has no FFI for this path: its boundary is the Python
+ * keyword call
+ *     librosa.feature.mfcc(y=samples.numpy(), n_fft=2048, hop_length=512, n_mfcc=13)
+ * at /root/reference/src/preprocess.py:134 (also :123), driven once per utterance by
+ * SpeechToTextTrainer.process_audio (/root/reference/src/preprocess.py:131-144) from the loop in
+ * SpeechToTextTrainer.preprocess (:146-167).  This header is the C-level equivalent of that
+ * call for a ragged BATCH of utterances; the Python host layer (speech_to_text_amd/) binds it
+ * with ctypes and mirrors the librosa keyword signature on top.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MFCC_E_* code; no exception crosses
+ *     the ABI; mfcc_last_error() returns a thread-local message for the last failure;
+ *   - the caller owns every device buffer; the library allocates device memory only inside
+ *     mfcc_plan_create (constant tables) and frees it in mfcc_plan_destroy;
+ *   - a plan is immutable after creation and may be shared by several streams, each with its
+ *     own workspace;
+ *   - "d_" parameters are device pointers, "h_" parameters are host pointers;
+ *   - audio is float32 PCM; utterance u occupies d_pcm[sample_offsets[u] .. sample_offsets[u+1]);
+ *     its features occupy rows frame_offsets[u] .. frame_offsets[u+1] of the (total_frames,
+ *     n_mfcc) row-major float32 output -- i.e. each utterance's slice is exactly the
+ *     C-contiguous (n_frames, n_mfcc) array that preprocess.py:135-139 writes to HDF5.
+ */
+#ifndef MFCC_HIP_H
+#define MFCC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFCC_ABI_VERSION 1
+
+enum {
+    MFCC_OK = 0,
+    MFCC_E_INVALID = -1,      /* bad argument (the librosa ParameterError cases) */
+    MFCC_E_UNSUPPORTED = -2,  /* valid librosa configuration this build has no kernel for */
+    MFCC_E_HIP = -3,          /* a HIP runtime call failed (no device, launch failure, ...) */
+    MFCC_E_WORKSPACE = -4,    /* workspace too small */
+    MFCC_E_NOMEM = -5
+};
+
+enum { MFCC_PAD_CONSTANT = 0, MFCC_PAD_REFLECT = 1 };
+enum { MFCC_MEL_NORM_NONE = 0, MFCC_MEL_NORM_SLANEY = 1 };
+enum { MFCC_DCT_NORM_NONE = 0, MFCC_DCT_NORM_ORTHO = 1 };
+
+/* Mirrors the keyword arguments of librosa.feature.mfcc -> melspectrogram -> stft ->
+ * filters.mel -> power_to_db (librosa 0.10.1).  mfcc_config_default() fills in librosa's
+ * defaults; the reference overrides n_fft=2048, hop_length=512, n_mfcc=13
+ * (/root/reference/src/preprocess.py:60-62) and leaves sr at librosa's 22050. */
+typedef struct mfcc_config {
+    int32_t struct_size;  /* = sizeof(mfcc_config); checked by mfcc_plan_create */
+    /* stft */
+    int32_t n_fft;        /* 2048 */
+    int32_t hop_length;   /* 512 */
+    int32_t win_length;   /* 0 -> n_fft */
+    int32_t center;       /* 1 */
+    int32_t pad_mode;     /* MFCC_PAD_CONSTANT (librosa 0.10 default) or MFCC_PAD_REFLECT */
+    float power;          /* 2.0: exponent applied to |STFT| */
+    /* filters.mel */
+    double sr;            /* 22050 */
+    int32_t n_mels;       /* 128 */
+    double fmin;          /* 0 */
+    double fmax;          /* <= 0 -> sr / 2 */
+    int32_t htk;          /* 0 */
+    int32_t mel_norm;     /* MFCC_MEL_NORM_SLANEY */
+    /* power_to_db */
+    float ref;            /* 1.0 */
+    float amin;           /* 1e-10 */
+    float top_db;         /* 80; negative -> None (no clamp) */
+    /* mfcc */
+    int32_t n_mfcc;       /* 20 */
+    int32_t dct_type;     /* 2 (1 and 3 also supported) */
+    int32_t dct_norm;     /* MFCC_DCT_NORM_ORTHO */
+    float lifter;         /* 0 */
+    /* optional overrides (host pointers, copied by mfcc_plan_create; NULL -> built-in) */
+    const double* window;    /* win_length float64 samples; NULL -> periodic Hann */
+    const float* mel_basis;  /* (n_mels, 1 + n_fft/2) row-major float32 */
+} mfcc_config;
+
+typedef struct mfcc_plan mfcc_plan;
+
+/* librosa defaults (n_mfcc = 20 etc.). */
+void mfcc_config_default(mfcc_config* cfg);
+
+/* ABI version, for the loader to check against MFCC_ABI_VERSION. */
+int mfcc_abi_version(void);
+
+/* Message for the calling thread's last failure ("" if none). */
+const char* mfcc_last_error(void);
+
+/* ---- host-only helpers (no GPU needed): the tables a plan uploads ---------------------- */
+/* n_fft float64 values: get_window(window, win_length, fftbins=True) zero-padded (centred) to
+ * n_fft, as librosa.stft builds it. */
+int mfcc_host_window(const mfcc_config* cfg, double* h_out);
+/* (n_mels, 1 + n_fft/2) float32: librosa.filters.mel. */
+int mfcc_host_mel_basis(const mfcc_config* cfg, float* h_out);
+/* (n_mfcc, n_mels) float32: rows of scipy.fftpack.dct(type, norm) applied along the mel axis. */
+int mfcc_host_dct_basis(const mfcc_config* cfg, float* h_out);
+/* Frames librosa produces for an utterance of n_samples (1 + n_samples // hop for centred,
+ * even n_fft); negative on error (center = 0 and n_samples < n_fft). */
+int64_t mfcc_num_frames(const mfcc_config* cfg, int64_t n_samples);
+/* frame_offsets[0] = 0, frame_offsets[u+1] = frame_offsets[u] + mfcc_num_frames(len_u). */
+int mfcc_batch_layout(const mfcc_config* cfg, const int64_t* h_sample_offsets, int32_t n_utts,
+                      int64_t* h_frame_offsets);
+
+/* ---- plan ------------------------------------------------------------------------------- */
+/* Builds and uploads window / twiddle / sparse-mel / DCT tables for the current HIP device.
+ * Replaces the per-call table construction inside librosa.feature.mfcc
+ * (/root/reference/src/preprocess.py:134 rebuilds the filterbank for every utterance). */
+int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan);
+void mfcc_plan_destroy(mfcc_plan* plan);
+
+/* Bytes of device workspace mfcc_execute needs for a batch of this size. */
+size_t mfcc_workspace_bytes(const mfcc_plan* plan, int64_t total_frames, int32_t n_utts);
+
+/* ---- execution -------------------------------------------------------------------------- */
+/* The whole pipeline of librosa.feature.mfcc for a ragged batch, asynchronous on `stream`
+ * (a hipStream_t, or NULL for the default stream):
+ *     pad -> frame -> window -> rFFT -> |.|^power -> mel filterbank -> power_to_db (top_db
+ *     against the maximum of each utterance's whole mel spectrogram) -> DCT -> [:n_mfcc] -> .T
+ * d_out            (total_frames, n_mfcc) float32, row-major.
+ * d_group          optional (n_utts) int32: utterances with the same value share one top_db
+ *                  maximum (the channels of one multi-channel librosa call); NULL -> every
+ *                  utterance is its own group.  Values must be in [0, n_utts).
+ * d_melspec_out    optional (total_frames, n_mels) float32: receives the mel power
+ *                  spectrogram (librosa.feature.melspectrogram, transposed); NULL -> the
+ *                  workspace holds it.
+ * Replaces: the loop of /root/reference/src/preprocess.py:146-167 calling :131-136. */
+int mfcc_execute(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sample_offsets,
+                 const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
+                 int64_t total_frames, float* d_out, float* d_melspec_out, void* d_workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* |STFT|^power only: d_spec_out is (total_frames, 1 + n_fft/2) float32 row-major, i.e.
+ * np.abs(librosa.stft(y))**power transposed (/root/reference/src/preprocess.py:111-113). */
+int mfcc_execute_spectrogram(const mfcc_plan* plan, const float* d_pcm,
+                             const int64_t* d_sample_offsets, const int64_t* d_frame_offsets,
+                             int32_t n_utts, int64_t total_frames, float* d_spec_out,
+                             void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---- global CMVN (extension; the reference does not normalise) -------------------------- */
+/* Adds, per coefficient, sum(x) and sum(x^2) over the rows of d_feats plus the row count
+ * into d_stats[0..n_mfcc), d_stats[n_mfcc..2 n_mfcc), d_stats[2 n_mfcc] (float64, caller
+ * zeroes them).  The caller all-reduces d_stats across GPUs (RCCL sum) and then applies. */
+int mfcc_cmvn_accumulate(const float* d_feats, int64_t n_rows, int32_t n_mfcc, double* d_stats,
+                         void* stream);
+/* In place: x = (x - mean) / sqrt(max(var, eps)) with mean/var from d_stats. */
+int mfcc_cmvn_apply(float* d_feats, int64_t n_rows, int32_t n_mfcc, const double* d_stats,
+                    double eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFCC_HIP_H */

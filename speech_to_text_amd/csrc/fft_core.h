@@ -1,0 +1,112 @@
+// In-register FFT building blocks shared by the gfx950 kernels and the host self-tests.
+//
+// Everything here is straight-line arithmetic on named scalars (arrays indexed only by
+// compile-time constants after unrolling), so on the device the data stays in VGPRs.
+//
+//   cfft16 : 16-point complex DFT, radix-4 x radix-4, decimation in frequency.
+//   rdft32 : 32-point DFT of a REAL sequence (bins 0..16) from one cfft16 of the packed
+//            sequence z[m] = r[2m] + i r[2m+1] plus the conjugate-symmetric split.
+//
+// Forward transform convention, as numpy.fft: X[k] = sum_n x[n] exp(-2 pi i n k / N).
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define FC_HD __host__ __device__ __forceinline__
+#else
+#define FC_HD inline
+#endif
+
+namespace fc {
+
+// exp(-2 pi i e / 16)
+constexpr float W16_1r = 0.9238795325112867f, W16_1i = -0.3826834323650898f;
+constexpr float W16_2r = 0.7071067811865476f, W16_2i = -0.7071067811865476f;
+constexpr float W16_3r = 0.3826834323650898f, W16_3i = -0.9238795325112867f;
+constexpr float W16_6r = -0.7071067811865476f, W16_6i = -0.7071067811865476f;
+constexpr float W16_9r = -0.9238795325112867f, W16_9i = 0.3826834323650898f;
+// exp(-2 pi i k / 32), k = 1..7
+constexpr float W32r[8] = {1.0f, 0.9807852804032304f, 0.9238795325112867f, 0.8314696123025452f,
+                           0.7071067811865476f, 0.5555702330196022f, 0.3826834323650898f,
+                           0.1950903220161283f};
+constexpr float W32i[8] = {0.0f, -0.1950903220161283f, -0.3826834323650898f, -0.5555702330196022f,
+                           -0.7071067811865476f, -0.8314696123025452f, -0.9238795325112867f,
+                           -0.9807852804032304f};
+
+// 4-point DFT in place: (a,b,c,d) = (x0,x1,x2,x3) -> (X0,X1,X2,X3).
+FC_HD void bfly4(float& ar, float& ai, float& br, float& bi, float& cr, float& ci, float& dr,
+                 float& di) {
+    const float s0r = ar + cr, s0i = ai + ci;  // x0 + x2
+    const float s1r = ar - cr, s1i = ai - ci;  // x0 - x2
+    const float s2r = br + dr, s2i = bi + di;  // x1 + x3
+    const float s3r = br - dr, s3i = bi - di;  // x1 - x3
+    ar = s0r + s2r; ai = s0i + s2i;            // X0
+    cr = s0r - s2r; ci = s0i - s2i;            // X2
+    br = s1r + s3i; bi = s1i - s3r;            // X1 = (x0-x2) - i (x1-x3)
+    dr = s1r - s3i; di = s1i + s3r;            // X3 = (x0-x2) + i (x1-x3)
+}
+
+FC_HD void cmul(float& xr, float& xi, const float wr, const float wi) {
+    const float tr = xr * wr - xi * wi;
+    const float ti = xr * wi + xi * wr;
+    xr = tr; xi = ti;
+}
+
+// Position in the cfft16 output arrays that holds bin k.
+constexpr int cfft16_pos(int k) { return (k >> 2) + 4 * (k & 3); }
+
+// 16-point complex DFT in place.  Input: re[n], im[n] in natural order.  Output: bin k is at
+// index cfft16_pos(k) (base-4 digit reversal).
+FC_HD void cfft16(float (&re)[16], float (&im)[16]) {
+    // Pass 1: for each n1, 4-point DFT over n2 of x[n1 + 4 n2]; t[n1][k2] lands at n1 + 4 k2.
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1)
+        bfly4(re[n1], im[n1], re[n1 + 4], im[n1 + 4], re[n1 + 8], im[n1 + 8], re[n1 + 12],
+              im[n1 + 12]);
+    // Twiddles W16^(n1 k2) at index n1 + 4 k2 (n1, k2 in 1..3).
+    cmul(re[5], im[5], W16_1r, W16_1i);     // n1=1,k2=1
+    cmul(re[6], im[6], W16_2r, W16_2i);     // n1=2,k2=1
+    cmul(re[7], im[7], W16_3r, W16_3i);     // n1=3,k2=1
+    cmul(re[9], im[9], W16_2r, W16_2i);     // n1=1,k2=2
+    {                                        // n1=2,k2=2 : W16^4 = -i
+        const float t = re[10]; re[10] = im[10]; im[10] = -t;
+    }
+    cmul(re[11], im[11], W16_6r, W16_6i);   // n1=3,k2=2
+    cmul(re[13], im[13], W16_3r, W16_3i);   // n1=1,k2=3
+    cmul(re[14], im[14], W16_6r, W16_6i);   // n1=2,k2=3
+    cmul(re[15], im[15], W16_9r, W16_9i);   // n1=3,k2=3
+    // Pass 2: for each k2, 4-point DFT over n1; X[4 k1 + k2] lands at k1 + 4 k2.
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2)
+        bfly4(re[4 * k2], im[4 * k2], re[4 * k2 + 1], im[4 * k2 + 1], re[4 * k2 + 2],
+              im[4 * k2 + 2], re[4 * k2 + 3], im[4 * k2 + 3]);
+}
+
+// DFT of a real 32-point sequence r[0..31].
+// On return, for k = 1..15 (k != 8):  (ar[k], ai[k]) = 2 * A[k];   (ar[8], ai[8]) = A[8];
+// and (ar[0], ai[0]) = (y_even, y_odd) where y_even = sum of r[even n] = (A[0]+A[16])/2 and
+// y_odd = sum of r[odd n] = (A[0]-A[16])/2 ... expressed through the packed transform as
+// Z[0] = (sum r[2m], sum r[2m+1]).  A[k] = sum_n r[n] exp(-2 pi i n k / 32).
+// The factors of two are absorbed by the caller's twiddle table.
+FC_HD void rdft32(const float (&r)[32], float (&ar)[16], float (&ai)[16]) {
+    float zr[16], zi[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { zr[m] = r[2 * m]; zi[m] = r[2 * m + 1]; }
+    cfft16(zr, zi);
+    ar[0] = zr[cfft16_pos(0)];
+    ai[0] = zi[cfft16_pos(0)];
+    ar[8] = zr[cfft16_pos(8)];               // A[8] = conj(Z[8])
+    ai[8] = -zi[cfft16_pos(8)];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const float a = zr[cfft16_pos(k)], b = zi[cfft16_pos(k)];
+        const float c = zr[cfft16_pos(16 - k)], d = zi[cfft16_pos(16 - k)];
+        const float er = a + c, ei = b - d;          // 2 E[k]
+        float tr = b + d, ti = c - a;                // 2 O[k] = -i (Z[k] - conj Z[16-k])
+        cmul(tr, ti, W32r[k], W32i[k]);              // 2 W32^k O[k]
+        ar[k] = er + tr;       ai[k] = ei + ti;      // 2 A[k]
+        ar[16 - k] = er - tr;  ai[16 - k] = ti - ei; // 2 A[16-k] = conj(2E - 2 W^k O)
+    }
+}
+
+}  // namespace fc

@@ -1,0 +1,207 @@
+// Host-side table construction (see host_tables.h).  Double precision throughout, rounded to
+// float32 exactly where librosa / scipy round.
+#include "host_tables.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace mfcc_host {
+
+static const double kPi = 3.14159265358979323846;
+
+std::string resolve(const mfcc_config* in, Resolved* out) {
+    if (!in) return "config is NULL";
+    if (in->struct_size != (int32_t)sizeof(mfcc_config))
+        return "mfcc_config.struct_size does not match this library (ABI mismatch)";
+    mfcc_config c = *in;
+    if (c.n_fft < 2) return "n_fft must be at least 2";
+    if (c.n_fft % 2) return "odd n_fft is not supported";
+    if (c.hop_length <= 0) return "hop_length must be a positive integer";
+    if (c.win_length == 0) c.win_length = c.n_fft;
+    if (c.win_length < 1 || c.win_length > c.n_fft)
+        return "win_length must be in [1, n_fft]";  // pad_center: target size >= input size
+    if (c.pad_mode != MFCC_PAD_CONSTANT && c.pad_mode != MFCC_PAD_REFLECT)
+        return "pad_mode must be 'constant' or 'reflect'";
+    if (!(c.power > 0.0f)) return "power must be positive";
+    if (!(c.sr > 0.0)) return "sr must be positive";
+    if (c.n_mels < 1) return "n_mels must be positive";
+    if (c.fmax <= 0.0) c.fmax = c.sr / 2.0;
+    if (!(c.amin > 0.0f)) return "amin must be strictly positive";
+    if (c.n_mfcc < 1 || c.n_mfcc > c.n_mels) return "n_mfcc must be in [1, n_mels]";
+    if (c.dct_type < 1 || c.dct_type > 3) return "dct_type must be 1, 2 or 3";
+    if (c.dct_type == 1 && c.n_mels < 2) return "DCT-I needs n_mels >= 2";
+    if (c.lifter < 0.0f) return "MFCC lifter must be a non-negative number";
+    if (c.mel_norm != MFCC_MEL_NORM_NONE && c.mel_norm != MFCC_MEL_NORM_SLANEY)
+        return "unsupported mel norm";
+    if (c.dct_norm != MFCC_DCT_NORM_NONE && c.dct_norm != MFCC_DCT_NORM_ORTHO)
+        return "unsupported dct norm";
+    out->c = c;
+    out->n_bins = 1 + c.n_fft / 2;
+    return "";
+}
+
+int64_t num_frames(const Resolved& r, int64_t n_samples) {
+    if (n_samples < 0) return -1;
+    int64_t padded = n_samples + (r.c.center ? 2 * (int64_t)(r.c.n_fft / 2) : 0);
+    if (padded < r.c.n_fft) return -1;
+    return 1 + (padded - r.c.n_fft) / r.c.hop_length;
+}
+
+// scipy.signal.get_window('hann', M, fftbins=True): the symmetric window of M+1 points,
+// 0.5 + 0.5 cos(linspace(-pi, pi, M+1)), without its last sample; then librosa pad_center.
+void build_window(const Resolved& r, std::vector<double>& w) {
+    const int n_fft = r.c.n_fft, wl = r.c.win_length;
+    w.assign(n_fft, 0.0);
+    const int lpad = (n_fft - wl) / 2;
+    for (int n = 0; n < wl; ++n) {
+        double v;
+        if (r.c.window) {
+            v = r.c.window[n];
+        } else if (wl == 1) {
+            v = 1.0;
+        } else {
+            const double step = (2.0 * kPi) / wl;
+            v = 0.5 + 0.5 * std::cos(-kPi + n * step);
+        }
+        w[lpad + n] = v;
+    }
+}
+
+static double hz_to_mel(double f, bool htk) {
+    if (htk) return 2595.0 * std::log10(1.0 + f / 700.0);
+    const double f_sp = 200.0 / 3;
+    const double min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = std::log(6.4) / 27.0;
+    if (f >= min_log_hz) return min_log_mel + std::log(f / min_log_hz) / logstep;
+    return f / f_sp;
+}
+
+static double mel_to_hz(double m, bool htk) {
+    if (htk) return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0);
+    const double f_sp = 200.0 / 3;
+    const double min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = std::log(6.4) / 27.0;
+    if (m >= min_log_mel) return min_log_hz * std::exp(logstep * (m - min_log_mel));
+    return f_sp * m;
+}
+
+void build_mel_basis(const Resolved& r, std::vector<float>& out) {
+    const int n_mels = r.c.n_mels, n_bins = r.n_bins, n_fft = r.c.n_fft;
+    out.assign((size_t)n_mels * n_bins, 0.0f);
+    if (r.c.mel_basis) {
+        std::copy(r.c.mel_basis, r.c.mel_basis + (size_t)n_mels * n_bins, out.begin());
+        return;
+    }
+    const bool htk = r.c.htk != 0;
+    // np.fft.rfftfreq(n, d): arange(n//2+1) * (1.0 / (n * d)), d = 1.0 / sr
+    const double val = 1.0 / (n_fft * (1.0 / r.c.sr));
+    std::vector<double> fftfreqs(n_bins);
+    for (int k = 0; k < n_bins; ++k) fftfreqs[k] = k * val;
+    // np.linspace(min_mel, max_mel, n_mels + 2)
+    const int npts = n_mels + 2;
+    const double min_mel = hz_to_mel(r.c.fmin, htk), max_mel = hz_to_mel(r.c.fmax, htk);
+    const double step = (max_mel - min_mel) / (npts - 1);
+    std::vector<double> mel_f(npts);
+    for (int i = 0; i < npts; ++i) {
+        const double m = (i == npts - 1) ? max_mel : i * step + min_mel;
+        mel_f[i] = mel_to_hz(m, htk);
+    }
+    for (int i = 0; i < n_mels; ++i) {
+        const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        for (int k = 0; k < n_bins; ++k) {
+            const double lower = -(mel_f[i] - fftfreqs[k]) / fd0;
+            const double upper = (mel_f[i + 2] - fftfreqs[k]) / fd1;
+            // weights[i] = np.maximum(0, np.minimum(lower, upper)) stored to a float32 array
+            float wv = (float)std::max(0.0, std::min(lower, upper));
+            // weights *= enorm[:, None]: float32 (x) float64 evaluated in double, stored float32
+            if (r.c.mel_norm == MFCC_MEL_NORM_SLANEY) wv = (float)((double)wv * enorm);
+            out[(size_t)i * n_bins + k] = wv;
+        }
+    }
+}
+
+void build_dct_basis(const Resolved& r, std::vector<float>& d) {
+    const int N = r.c.n_mels, K = r.c.n_mfcc;
+    const bool ortho = r.c.dct_norm == MFCC_DCT_NORM_ORTHO;
+    d.assign((size_t)K * N, 0.0f);
+    for (int k = 0; k < K; ++k) {
+        for (int n = 0; n < N; ++n) {
+            double v = 0.0;
+            if (r.c.dct_type == 2) {
+                v = 2.0 * std::cos(kPi * k * (2.0 * n + 1.0) / (2.0 * N));
+                if (ortho) v *= (k == 0) ? std::sqrt(1.0 / (4.0 * N)) : std::sqrt(1.0 / (2.0 * N));
+            } else if (r.c.dct_type == 3) {
+                if (ortho)
+                    v = (n == 0) ? 1.0 / std::sqrt((double)N)
+                                 : std::sqrt(2.0 / N) * std::cos(kPi * (2.0 * k + 1.0) * n / (2.0 * N));
+                else
+                    v = (n == 0) ? 1.0 : 2.0 * std::cos(kPi * (2.0 * k + 1.0) * n / (2.0 * N));
+            } else {  // type 1
+                const double c = std::cos(kPi * k * n / (N - 1.0));
+                if (n == 0) v = 1.0;
+                else if (n == N - 1) v = (k % 2) ? -1.0 : 1.0;
+                else v = 2.0 * c;
+                if (ortho) {
+                    if (n == 0 || n == N - 1) v *= std::sqrt(2.0);
+                    v *= std::sqrt(1.0 / (2.0 * (N - 1.0)));
+                    if (k == 0 || k == N - 1) v *= 1.0 / std::sqrt(2.0);
+                }
+            }
+            d[(size_t)k * N + n] = (float)v;
+        }
+    }
+}
+
+// librosa.feature.mfcc: M *= 1 + (lifter / 2) * sin(pi * arange(1, 1 + n_mfcc, float32) / lifter)
+void build_lifter(const Resolved& r, std::vector<float>& l) {
+    l.assign(r.c.n_mfcc, 1.0f);
+    if (r.c.lifter > 0.0f) {
+        for (int k = 0; k < r.c.n_mfcc; ++k) {
+            const float a = (float)(kPi) * (float)(k + 1) / r.c.lifter;
+            l[k] = 1.0f + (r.c.lifter / 2.0f) * std::sin(a);
+        }
+    }
+}
+
+void build_sparse_mel(const std::vector<float>& basis, int n_mels, int n_bins, SparseMel& s) {
+    std::vector<int> first(n_mels, 0), len(n_mels, 0);
+    for (int m = 0; m < n_mels; ++m) {
+        int lo = -1, hi = -1;
+        for (int k = 0; k < n_bins; ++k)
+            if (basis[(size_t)m * n_bins + k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
+        first[m] = lo < 0 ? 0 : lo;
+        len[m] = lo < 0 ? 0 : hi - lo + 1;
+    }
+    std::vector<int> order(n_mels);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
+    s.n_pass = (n_mels + 63) / 64;
+    s.rounds.assign(s.n_pass, 0);
+    s.round_off.assign(s.n_pass, 0);
+    s.start.assign((size_t)s.n_pass * 64, 0);
+    s.filt.assign((size_t)s.n_pass * 64, -1);
+    s.total_rounds = 0;
+    s.max_read = 0;
+    for (int p = 0; p < s.n_pass; ++p) {
+        int mx = 0;
+        for (int l = 0; l < 64 && p * 64 + l < n_mels; ++l) mx = std::max(mx, len[order[p * 64 + l]]);
+        s.rounds[p] = (mx + 3) / 4 * 4;
+        s.round_off[p] = s.total_rounds;
+        s.total_rounds += s.rounds[p];
+    }
+    s.w.assign((size_t)s.total_rounds * 64, 0.0f);
+    for (int p = 0; p < s.n_pass; ++p) {
+        for (int l = 0; l < 64 && p * 64 + l < n_mels; ++l) {
+            const int m = order[p * 64 + l];
+            s.filt[p * 64 + l] = m;
+            s.start[p * 64 + l] = first[m];
+            for (int i = 0; i < len[m]; ++i)
+                s.w[(size_t)(s.round_off[p] + i) * 64 + l] = basis[(size_t)m * n_bins + first[m] + i];
+            if (s.rounds[p] > 0) s.max_read = std::max(s.max_read, first[m] + s.rounds[p] - 1);
+        }
+    }
+}
+
+}  // namespace mfcc_host

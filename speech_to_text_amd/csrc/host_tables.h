@@ -1,0 +1,46 @@
+// Host-side (CPU, double precision) construction of the constant tables a plan uploads:
+// the analysis window, the mel filterbank, the DCT basis and their device-friendly packings.
+// Restates librosa 0.10.1 filters.get_window / filters.mel / convert.mel_frequencies and
+// scipy.fftpack.dct; the call that needs them is /root/reference/src/preprocess.py:134.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mfcc_hip.h"
+
+namespace mfcc_host {
+
+// Validated, defaults-resolved copy of an mfcc_config (win_length, fmax filled in).
+struct Resolved {
+    mfcc_config c;
+    int n_bins;  // 1 + n_fft / 2
+};
+
+// Returns "" on success, else the reason (the librosa ParameterError cases).
+std::string resolve(const mfcc_config* in, Resolved* out);
+
+void build_window(const Resolved& r, std::vector<double>& w);        // n_fft values
+void build_mel_basis(const Resolved& r, std::vector<float>& m);      // n_mels x n_bins
+void build_dct_basis(const Resolved& r, std::vector<float>& d);      // n_mfcc x n_mels
+void build_lifter(const Resolved& r, std::vector<float>& l);         // n_mfcc factors
+
+int64_t num_frames(const Resolved& r, int64_t n_samples);
+
+// Sparse packing of the mel filterbank for the lane-per-filter contraction.
+// Filters are sorted by support length (longest first) and dealt 64 per pass; in pass p lane l
+// owns filter filt[p*64+l] (or -1), reads bins start[p*64+l] + i for i in [0, rounds[p]) and
+// multiplies by w[(round_off[p] + i) * 64 + l] (zero outside the filter's support).
+struct SparseMel {
+    int n_pass = 0;
+    std::vector<int> rounds;     // per pass, a multiple of 4
+    std::vector<int> round_off;  // per pass, prefix sum of rounds
+    std::vector<int32_t> start;  // n_pass * 64
+    std::vector<int32_t> filt;   // n_pass * 64
+    std::vector<float> w;        // total_rounds * 64
+    int total_rounds = 0;
+    int max_read = 0;            // largest bin index any lane reads
+};
+void build_sparse_mel(const std::vector<float>& basis, int n_mels, int n_bins, SparseMel& s);
+
+}  // namespace mfcc_host

@@ -1,0 +1,296 @@
+"""Host-side mirror of the librosa calls the reference makes, running on libmfcc_hip.
+
+``mfcc`` keeps the keyword signature of ``librosa.feature.mfcc`` as called at
+/root/reference/src/preprocess.py:134 (``y, n_fft, hop_length, n_mfcc`` plus the librosa
+defaults); ``mfcc_batch`` is the ragged-batch form the GPU wants; ``melspectrogram`` and
+``spectrogram`` are the intermediate taps (/root/reference/src/preprocess.py:111-113).
+
+PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+import warnings
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import MfccConfig, ParameterError, make_config
+
+
+def _device(device=None) -> torch.device:
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("speech_to_text_amd needs a ROCm GPU: there is no CPU fallback")
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device(device)
+
+
+class MfccPlan:
+    """Device tables for one MfccConfig on one GPU (``mfcc_plan_create``)."""
+
+    def __init__(self, config: MfccConfig, device=None):
+        self.config = config
+        self.device = _device(device)
+        self._handle = C.c_void_p()
+        cfg_c, keep = config.to_c()
+        self._cfg_c, self._keep = cfg_c, keep
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mfcc_plan_create(C.byref(cfg_c), C.byref(self._handle)))
+        self._ws: Optional[torch.Tensor] = None
+
+    def close(self):
+        if self._handle:
+            _lib.lib().mfcc_plan_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------
+    def num_frames(self, n_samples: int) -> int:
+        F = _lib.lib().mfcc_num_frames(C.byref(self._cfg_c), int(n_samples))
+        if F < 0:
+            raise ParameterError(_lib.last_error())
+        return int(F)
+
+    def frame_offsets(self, sample_offsets: np.ndarray) -> np.ndarray:
+        so = np.ascontiguousarray(sample_offsets, dtype=np.int64)
+        fo = np.zeros_like(so)
+        rc = _lib.lib().mfcc_batch_layout(C.byref(self._cfg_c), so.ctypes.data_as(C.POINTER(C.c_int64)),
+                                          len(so) - 1, fo.ctypes.data_as(C.POINTER(C.c_int64)))
+        if rc == _lib.MFCC_E_INVALID:
+            raise ParameterError(_lib.last_error())
+        _lib.check(rc)
+        return fo
+
+    def workspace(self, total_frames: int, n_utts: int) -> torch.Tensor:
+        need = int(_lib.lib().mfcc_workspace_bytes(self._handle, int(total_frames), int(n_utts)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ------------------------------------------------------------------------------------
+    def execute(self, pcm: torch.Tensor, sample_offsets: torch.Tensor, frame_offsets: torch.Tensor,
+                total_frames: int, *, group: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None, melspec_out: Optional[torch.Tensor] = None,
+                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Run the whole pipeline on device-resident buffers; asynchronous on the current
+        stream.  Returns the (total_frames, n_mfcc) float32 tensor."""
+        n_utts = sample_offsets.numel() - 1
+        assert pcm.dtype == torch.float32 and pcm.is_contiguous() and pcm.device == self.device
+        assert sample_offsets.dtype == torch.int64 and frame_offsets.dtype == torch.int64
+        if out is None:
+            out = torch.empty((total_frames, self.config.n_mfcc), dtype=torch.float32, device=self.device)
+        ws = workspace if workspace is not None else self.workspace(total_frames, n_utts)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(_lib.lib().mfcc_execute(
+                self._handle, pcm.data_ptr(), sample_offsets.data_ptr(), frame_offsets.data_ptr(),
+                group.data_ptr() if group is not None else None, n_utts, int(total_frames),
+                out.data_ptr(), melspec_out.data_ptr() if melspec_out is not None else None,
+                ws.data_ptr(), ws.numel(), stream))
+        return out
+
+    def execute_spectrogram(self, pcm, sample_offsets, frame_offsets, total_frames, *, out=None,
+                            workspace=None) -> torch.Tensor:
+        n_utts = sample_offsets.numel() - 1
+        n_bins = 1 + self.config.n_fft // 2
+        if out is None:
+            out = torch.empty((total_frames, n_bins), dtype=torch.float32, device=self.device)
+        ws = workspace if workspace is not None else self.workspace(total_frames, n_utts)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(_lib.lib().mfcc_execute_spectrogram(
+                self._handle, pcm.data_ptr(), sample_offsets.data_ptr(), frame_offsets.data_ptr(),
+                n_utts, int(total_frames), out.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        return out
+
+
+_PLANS = {}
+_PLANS_LOCK = threading.Lock()
+
+
+def get_plan(config: MfccConfig, device=None) -> MfccPlan:
+    """Plans are cached per (config, device): librosa rebuilds its filterbank on every call
+    (/root/reference/src/preprocess.py:134), this engine builds its tables once."""
+    dev = _device(device)
+    key = (config, dev.index)
+    with _PLANS_LOCK:
+        plan = _PLANS.get(key)
+        if plan is None:
+            plan = MfccPlan(config, dev)
+            _PLANS[key] = plan
+        return plan
+
+
+# --------------------------------------------------------------------------------------------
+def _as_float_array(y):
+    if isinstance(y, torch.Tensor):
+        if not y.dtype.is_floating_point:
+            raise ParameterError("Audio data must be floating-point")
+        return y
+    if not isinstance(y, np.ndarray):
+        raise ParameterError("Audio data must be of type numpy.ndarray")
+    if not np.issubdtype(y.dtype, np.floating):
+        raise ParameterError("Audio data must be floating-point")
+    return y
+
+
+def _valid_audio(y) -> None:
+    """librosa.util.valid_audio: floating point and finite everywhere."""
+    if y.ndim == 0:
+        raise ParameterError(f"Audio data must be at least one-dimensional, given y.shape={tuple(y.shape)}")
+    finite = bool(torch.isfinite(y).all()) if isinstance(y, torch.Tensor) else bool(np.isfinite(y).all())
+    if not finite:
+        raise ParameterError("Audio buffer is not finite everywhere")
+
+
+def _upload_ragged(chans: Sequence, device) -> (torch.Tensor, np.ndarray):
+    lens = np.array([int(c.shape[-1]) for c in chans], dtype=np.int64)
+    so = np.zeros(len(chans) + 1, dtype=np.int64)
+    np.cumsum(lens, out=so[1:])
+    total = int(so[-1])
+    if all(isinstance(c, torch.Tensor) and c.is_cuda for c in chans) and len(chans) > 0:
+        pcm = torch.cat([c.reshape(-1).to(device=device, dtype=torch.float32) for c in chans]) if total else \
+            torch.empty(0, dtype=torch.float32, device=device)
+    else:
+        host = np.empty(total, dtype=np.float32)
+        for c, a, b in zip(chans, so[:-1], so[1:]):
+            host[a:b] = c.detach().cpu().numpy().reshape(-1) if isinstance(c, torch.Tensor) else np.asarray(c).reshape(-1)
+        pcm = torch.from_numpy(host).to(device)
+    if pcm.numel() == 0:
+        pcm = torch.zeros(1, dtype=torch.float32, device=device)
+    return pcm, so
+
+
+def _run_batch(chans: Sequence, config: MfccConfig, *, groups: Optional[np.ndarray], device,
+               what: str = "mfcc"):
+    """chans: 1-D arrays.  Returns (device tensor (total_frames, width), frame_offsets)."""
+    plan = get_plan(config, device)
+    for c in chans:
+        if config.center and config.n_fft > c.shape[-1]:
+            warnings.warn(f"n_fft={config.n_fft} is too large for input signal of length={c.shape[-1]}",
+                          stacklevel=3)
+        if config.center and config.pad_mode == "reflect" and c.shape[-1] == 0:
+            raise ParameterError("can't extend an empty signal with pad_mode='reflect'")
+    pcm, so = _upload_ragged(chans, plan.device)
+    fo = plan.frame_offsets(so)
+    total_frames = int(fo[-1])
+    d_so = torch.from_numpy(so).to(plan.device)
+    d_fo = torch.from_numpy(fo).to(plan.device)
+    if what == "spectrogram":
+        out = plan.execute_spectrogram(pcm, d_so, d_fo, total_frames)
+        return out, fo
+    d_grp = torch.from_numpy(np.ascontiguousarray(groups, dtype=np.int32)).to(plan.device) if groups is not None else None
+    if what == "melspectrogram":
+        mel = torch.empty((total_frames, config.n_mels), dtype=torch.float32, device=plan.device)
+        plan.execute(pcm, d_so, d_fo, total_frames, group=d_grp, melspec_out=mel)
+        return mel, fo
+    out = plan.execute(pcm, d_so, d_fo, total_frames, group=d_grp)
+    return out, fo
+
+
+def _split_kwargs(sr, n_mfcc, dct_type, norm, lifter, kwargs) -> MfccConfig:
+    kw = dict(kwargs)
+    if "norm" in kw:  # melspectrogram's **kwargs reach filters.mel, whose `norm` is the mel norm
+        raise ParameterError("pass the mel filterbank norm as mel_norm=...")
+    return make_config(sr=sr, n_mfcc=n_mfcc, dct_type=dct_type, norm=norm, lifter=lifter, **kw)
+
+
+def _channels_of(y):
+    """(..., T) -> list of 1-D channel views, leading shape."""
+    lead = tuple(y.shape[:-1])
+    flat = y.reshape(-1, y.shape[-1]) if y.ndim > 1 else y.reshape(1, -1)
+    return [flat[i] for i in range(flat.shape[0])], lead
+
+
+def mfcc(*, y=None, sr=22050, S=None, n_mfcc=20, dct_type=2, norm="ortho", lifter=0, device=None,
+         validate=True, **kwargs) -> np.ndarray:
+    """Drop-in for ``librosa.feature.mfcc(y=..., ...)``: returns float32 of shape
+    ``y.shape[:-1] + (n_mfcc, n_frames)``.
+
+    ``kwargs`` are melspectrogram / stft / filters.mel keywords (n_fft, hop_length, win_length,
+    window, center, pad_mode, power, n_mels, fmin, fmax, htk; the mel norm is ``mel_norm``).
+    As in librosa, power_to_db runs with ref=1.0, amin=1e-10, top_db=80.0 and the top_db maximum
+    is taken over the whole array passed in (all channels).
+    """
+    if S is not None:
+        raise NotImplementedError("mfcc(S=...) is not on the reference's path "
+                                  "(/root/reference/src/preprocess.py:134 passes y)")
+    if y is None:
+        raise ParameterError("y must be given")
+    y = _as_float_array(y)
+    if validate:
+        _valid_audio(y)
+    config = _split_kwargs(sr, n_mfcc, dct_type, norm, lifter, kwargs)
+    chans, lead = _channels_of(y)
+    out, fo = _run_batch(chans, config, groups=np.zeros(len(chans), dtype=np.int32), device=device)
+    F = int(fo[1] - fo[0]) if len(chans) else 0
+    res = out.reshape(len(chans), F, config.n_mfcc).cpu().numpy()
+    return res.transpose(0, 2, 1).reshape(lead + (config.n_mfcc, F))
+
+
+def melspectrogram(*, y=None, sr=22050, device=None, validate=True, **kwargs) -> np.ndarray:
+    """``librosa.feature.melspectrogram(y=...)``: ``y.shape[:-1] + (n_mels, n_frames)``."""
+    y = _as_float_array(y)
+    if validate:
+        _valid_audio(y)
+    config = make_config(sr=sr, **kwargs)
+    chans, lead = _channels_of(y)
+    out, fo = _run_batch(chans, config, groups=None, device=device, what="melspectrogram")
+    F = int(fo[1] - fo[0]) if len(chans) else 0
+    res = out.reshape(len(chans), F, config.n_mels).cpu().numpy()
+    return res.transpose(0, 2, 1).reshape(lead + (config.n_mels, F))
+
+
+def spectrogram(*, y=None, n_fft=2048, hop_length=512, power=1.0, device=None, validate=True,
+                **kwargs) -> np.ndarray:
+    """``np.abs(librosa.stft(y, ...)) ** power``: ``y.shape[:-1] + (1 + n_fft//2, n_frames)``
+    (/root/reference/src/preprocess.py:111-113 uses power=1)."""
+    y = _as_float_array(y)
+    if validate:
+        _valid_audio(y)
+    config = make_config(n_fft=n_fft, hop_length=hop_length, power=power, **kwargs)
+    chans, lead = _channels_of(y)
+    out, fo = _run_batch(chans, config, groups=None, device=device, what="spectrogram")
+    F = int(fo[1] - fo[0]) if len(chans) else 0
+    nb = 1 + config.n_fft // 2
+    res = out.reshape(len(chans), F, nb).cpu().numpy()
+    return res.transpose(0, 2, 1).reshape(lead + (nb, F))
+
+
+def mfcc_batch(ys: Sequence, *, sr=22050, n_mfcc=20, dct_type=2, norm="ortho", lifter=0, device=None,
+               validate=True, return_tensor=False, **kwargs) -> List:
+    """Ragged batch: ``ys`` is a sequence of mono utterances, each ``(T_i,)`` or ``(1, T_i)``
+    (the waveform layout of a LibriSpeech item, /root/reference/src/preprocess.py:132).
+
+    Returns one ``(n_frames_i, n_mfcc)`` float32 C-contiguous array per utterance -- exactly
+    ``librosa.feature.mfcc(y=y_i, ...)[0].T`` as written to HDF5 at
+    /root/reference/src/preprocess.py:135-139.  Each utterance has its own top_db maximum.
+    """
+    config = _split_kwargs(sr, n_mfcc, dct_type, norm, lifter, kwargs)
+    chans = []
+    for y in ys:
+        y = _as_float_array(y)
+        if y.ndim == 2 and y.shape[0] == 1:
+            y = y[0]
+        if y.ndim != 1:
+            raise ParameterError(f"mfcc_batch takes mono utterances, got shape {tuple(y.shape)}")
+        if validate:
+            _valid_audio(y)
+        chans.append(y)
+    if not chans:
+        return []
+    out, fo = _run_batch(chans, config, groups=None, device=device)
+    if return_tensor:
+        return [out[int(a):int(b)] for a, b in zip(fo[:-1], fo[1:])]
+    host = out.cpu().numpy()
+    return [host[int(a):int(b)] for a, b in zip(fo[:-1], fo[1:])]

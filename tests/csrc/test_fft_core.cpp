@@ -1,0 +1,46 @@
+// Host self-test of the in-register FFT building blocks against a direct O(N^2) DFT in double.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include "../../speech_to_text_amd/csrc/fft_core.h"
+
+int main() {
+    const double PI = 3.14159265358979323846;
+    double worst = 0.0;
+    srand(7);
+    for (int trial = 0; trial < 50; ++trial) {
+        float re[16], im[16]; double xr[16], xi[16];
+        for (int n = 0; n < 16; ++n) {
+            xr[n] = re[n] = (float)rand() / RAND_MAX - 0.5f;
+            xi[n] = im[n] = (float)rand() / RAND_MAX - 0.5f;
+        }
+        fc::cfft16(re, im);
+        for (int k = 0; k < 16; ++k) {
+            double sr = 0, si = 0;
+            for (int n = 0; n < 16; ++n) {
+                const double c = cos(2 * PI * n * k / 16), s = -sin(2 * PI * n * k / 16);
+                sr += xr[n] * c - xi[n] * s; si += xr[n] * s + xi[n] * c;
+            }
+            worst = fmax(worst, fabs(sr - re[fc::cfft16_pos(k)]));
+            worst = fmax(worst, fabs(si - im[fc::cfft16_pos(k)]));
+        }
+        float r[32], ar[16], ai[16]; double rd[32];
+        for (int n = 0; n < 32; ++n) rd[n] = r[n] = (float)rand() / RAND_MAX - 0.5f;
+        fc::rdft32(r, ar, ai);
+        double A0 = 0, A16 = 0;
+        for (int n = 0; n < 32; ++n) { A0 += rd[n]; A16 += (n & 1) ? -rd[n] : rd[n]; }
+        worst = fmax(worst, fabs((A0 + A16) / 2 - ar[0]));
+        worst = fmax(worst, fabs((A0 - A16) / 2 - ai[0]));
+        for (int k = 1; k < 16; ++k) {
+            double sr = 0, si = 0;
+            for (int n = 0; n < 32; ++n) {
+                sr += rd[n] * cos(2 * PI * n * k / 32); si -= rd[n] * sin(2 * PI * n * k / 32);
+            }
+            const double sc = (k == 8) ? 1.0 : 2.0;
+            worst = fmax(worst, fabs(sc * sr - ar[k]));
+            worst = fmax(worst, fabs(sc * si - ai[k]));
+        }
+    }
+    printf("max_abs_err %.3e\n", worst);
+    return worst < 5e-6 ? 0 : 1;
+}
