@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-hours of MFCC per second on MI355X.
+
+One "step" = one pass of the hot path (pad/frame/window/FFT/mel/dB/DCT) over one device-resident
+batch of synthetic 16 kHz utterances with the reference's settings (n_fft=2048, hop=512,
+128 mels, 13 MFCC; /root/reference/src/preprocess.py:60-62,134).  N=1 workload: BASELINE.json
+configs[1], a 10-hour ragged batch (2-35 s utterances, "LibriLight-limited-10h stand-in").
+N>1: every rank processes its own 10-hour shard (independent utterances, no collective on the
+data path) -> weak scaling; value = all ranks' audio-hours / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--hours H]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+SR = 16000
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def make_batch(hours: float, seed: int, device, lo_s=2.0, hi_s=35.0):
+    """Ragged synthetic batch generated on the device: speech-like = amplitude-modulated noise
+    plus a 220 Hz tone, on the int16 grid like LibriSpeech PCM."""
+    rng = np.random.default_rng(seed)
+    target = int(hours * 3600 * SR)
+    lens = []
+    tot = 0
+    while tot < target:
+        n = int(rng.uniform(lo_s, hi_s) * SR)
+        n = min(n, target - tot) if target - tot >= int(lo_s * SR) else n
+        lens.append(n)
+        tot += n
+    lens = np.asarray(lens, dtype=np.int64)
+    so = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=so[1:])
+    total = int(so[-1])
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    pcm = torch.empty(total, dtype=torch.float32, device=device)
+    chunk = 1 << 26
+    for a in range(0, total, chunk):
+        b = min(a + chunk, total)
+        t = torch.arange(a, b, device=device, dtype=torch.float64) / SR
+        noise = torch.randn(b - a, generator=g, device=device, dtype=torch.float32)
+        env = torch.sin(2 * np.pi * 1.5 * t).abs().float()
+        tone = torch.sin(2 * np.pi * 220.0 * t).float()
+        y = (0.1 * noise * env + 0.3 * tone).clamp_(-0.999, 0.999)
+        pcm[a:b] = torch.round(y * 32768.0) / 32768.0
+        del t, noise, env, tone, y
+    return pcm, so
+
+
+def cpu_baseline(pcm, so, fo, gpu_out, sample_hours=0.5):
+    """Times the CPU oracle (restatement of librosa 0.10.1; librosa is not installed) on a bounded
+    sample of the same utterances, one core, and checks the GPU result against it."""
+    from oracle import mfcc_ref as R
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    n = 0
+    while n < len(so) - 1 and so[n + 1] < sample_hours * 3600 * SR:
+        n += 1
+    n = max(n, 1)
+    host = pcm[: int(so[n])].cpu().numpy()
+    utts = [host[int(so[i]): int(so[i + 1])] for i in range(n)]
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        R.process_audio_features(utts[0])  # warm caches / imports
+        t0 = time.perf_counter()
+        feats = [R.process_audio_features(u) for u in utts]
+        dt = time.perf_counter() - t0
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    hours = float(so[n]) / SR / 3600.0
+    worst = 0.0
+    got = gpu_out[: int(fo[n])].cpu().numpy()
+    for i, f in enumerate(feats):
+        worst = max(worst, float(np.abs(got[int(fo[i]): int(fo[i + 1])] - f).max()))
+    return {
+        "value": hours / dt,
+        "unit": "audio-hours/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {n} utterances ({hours:.3f} audio-hours) of the same batch, "
+                  f"numpy/scipy restatement of librosa 0.10.1 (librosa not installed), 1 thread",
+        "seconds": dt,
+        "max_abs_diff_vs_gpu_db": worst,
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--hours", type=float, default=10.0, help="audio-hours per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks "
+                         f"(WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import speech_to_text_amd as S
+
+    config = S.MfccConfig.reference_default()
+    plan = S.get_plan(config, device)
+    pcm, so = make_batch(args.hours, seed=1234 + rank, device=device)
+    fo = plan.frame_offsets(so)
+    total_frames = int(fo[-1])
+    total_samples = int(so[-1])
+    d_so = torch.from_numpy(so).to(device)
+    d_fo = torch.from_numpy(fo).to(device)
+    out = torch.empty((total_frames, config.n_mfcc), dtype=torch.float32, device=device)
+    ws = plan.workspace(total_frames, len(so) - 1)
+    plan.set_profiling(True)
+
+    def step():
+        plan.execute(pcm, d_so, d_fo, total_frames, out=out, workspace=ws)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    front_ms, dct_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        a, b = plan.last_timings()      # HIP events on the launch stream; waits for this step
+        front_ms.append(a)
+        dct_ms.append(b)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    hours_per_step = world * total_samples / SR / 3600.0 if world == 1 else None
+    if world > 1:
+        h = torch.tensor([total_samples / SR / 3600.0], dtype=torch.float64, device=device)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        hours_per_step = float(h.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = hours_per_step / (ms_per_step / 1e3)
+
+    if rank == 0:
+        # Dominant kernel: the front end (PCM -> mel power).  Algorithmic bytes per launch:
+        # every PCM sample read once + every mel value written once.
+        front = float(np.mean(front_ms))
+        dctm = float(np.mean(dct_ms))
+        alg_front = 4.0 * total_samples + 4.0 * config.n_mels * total_frames
+        alg_e2e = 4.0 * total_samples + 4.0 * config.n_mfcc * total_frames
+        achieved = alg_front / (front * 1e-3) / 1e9
+        # FFT-dominated flop model per frame (2.5 N log2 N + 3 B + 2 nnz(mel))
+        flops_frame = 2.5 * 2048 * 11 + 3 * 1025 + 2 * 2018
+        line = {
+            "metric": "audio-hours of MFCC/sec",
+            "value": value,
+            "unit": "audio-hours/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1]: {args.hours:g} h synthetic 16 kHz ragged 2-35 s "
+                            f"utterances per GPU, n_fft=2048 hop=512 n_mels=128 n_mfcc=13, "
+                            f"device-resident PCM, one batch per step",
+                "utterances_per_gpu": int(len(so) - 1),
+                "frames_per_gpu": total_frames,
+                "parallelism": f"utterance-sharded x{world}, no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_melspec_2048 (pad+frame+window+rFFT+power+mel)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms": front,
+                "algorithmic_bytes_per_launch": alg_front,
+                "end_to_end_GBps": alg_e2e / ((front + dctm) * 1e-3) / 1e9,
+                "db_dct_kernel_ms": dctm,
+                "fp32_valu_tflops": flops_frame * total_frames / (front * 1e-3) / 1e12,
+                "fp32_valu_peak_tflops": FP32_VALU_PEAK_TFLOPS,
+            },
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pcm, so, fo, out)
+            line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

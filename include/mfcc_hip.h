@@ -142,6 +142,14 @@ int mfcc_execute_spectrogram(const mfcc_plan* plan, const float* d_pcm,
                              int32_t n_utts, int64_t total_frames, float* d_spec_out,
                              void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ---- measurement ------------------------------------------------------------------------- */
+/* With profiling enabled, mfcc_execute records HIP events on its stream around the front-end
+ * kernel (pad/frame/window/FFT/mel) and the dB+DCT kernel; mfcc_plan_last_timings waits for the
+ * last call and returns both durations in milliseconds.  One execute in flight per plan while
+ * profiling.  No counterpart in the reference (it has no timing code). */
+int mfcc_plan_set_profiling(mfcc_plan* plan, int enable);
+int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_dct);
+
 /* ---- global CMVN (extension; the reference does not normalise) -------------------------- */
 /* Adds, per coefficient, sum(x) and sum(x^2) over the rows of d_feats plus the row count
  * into d_stats[0..n_mfcc), d_stats[n_mfcc..2 n_mfcc), d_stats[2 n_mfcc] (float64, caller

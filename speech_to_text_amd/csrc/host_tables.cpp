@@ -165,18 +165,48 @@ void build_lifter(const Resolved& r, std::vector<float>& l) {
     }
 }
 
-void build_sparse_mel(const std::vector<float>& basis, int n_mels, int n_bins, SparseMel& s) {
-    std::vector<int> first(n_mels, 0), len(n_mels, 0);
+// ds_read_b128 services a wavefront in four groups of 16 lanes; only lanes of one group can
+// bank-conflict, and they do not if their 16-byte slots differ modulo 16.
+static const int kB128Groups[4][16] = {
+    {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+    {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+    {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+
+namespace {
+// Kuhn's bipartite matching: filters of one pass -> (lane group, slot residue) pairs.
+struct Matcher {
+    int n;                                   // filters in the pass
+    std::vector<std::vector<int>> feas;      // feasible residues per filter
+    int owner[4][16];
+    bool try_assign(int i, bool (&seen)[4][16]) {
+        for (int g = 0; g < 4; ++g)
+            for (int r : feas[i]) {
+                if (seen[g][r]) continue;
+                seen[g][r] = true;
+                if (owner[g][r] < 0 || try_assign(owner[g][r], seen)) { owner[g][r] = i; return true; }
+            }
+        return false;
+    }
+};
+}  // namespace
+
+void build_sparse_mel(const std::vector<float>& basis, int n_mels, int n_bins, int chunk_quads, SparseMel& s) {
+    std::vector<int> first(n_mels, 0), last(n_mels, -1);
     for (int m = 0; m < n_mels; ++m) {
         int lo = -1, hi = -1;
         for (int k = 0; k < n_bins; ++k)
             if (basis[(size_t)m * n_bins + k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
         first[m] = lo < 0 ? 0 : lo;
-        len[m] = lo < 0 ? 0 : hi - lo + 1;
+        last[m] = lo < 0 ? -1 : hi;
     }
+    auto quads = [&](int m) { return last[m] < 0 ? 0 : last[m] / 4 - first[m] / 4 + 1; };
     std::vector<int> order(n_mels);
     std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return quads(a) > quads(b); });
+    // Bins are read four at a time (ds_read_b128): a lane starts at a multiple of 4 at or below
+    // its filter's first non-zero bin, possibly earlier (zero weights) so that the lanes of each
+    // 16-lane group hit distinct LDS bank groups.
     s.n_pass = (n_mels + 63) / 64;
     s.rounds.assign(s.n_pass, 0);
     s.round_off.assign(s.n_pass, 0);
@@ -184,22 +214,88 @@ void build_sparse_mel(const std::vector<float>& basis, int n_mels, int n_bins, S
     s.filt.assign((size_t)s.n_pass * 64, -1);
     s.total_rounds = 0;
     s.max_read = 0;
+    std::vector<std::vector<int>> pass_lane_filter(s.n_pass, std::vector<int>(64, -1));
+    std::vector<std::vector<int>> pass_lane_start(s.n_pass, std::vector<int>(64, 0));
     for (int p = 0; p < s.n_pass; ++p) {
-        int mx = 0;
-        for (int l = 0; l < 64 && p * 64 + l < n_mels; ++l) mx = std::max(mx, len[order[p * 64 + l]]);
-        s.rounds[p] = (mx + 3) / 4 * 4;
+        const int nf = std::min(64, n_mels - p * 64);
+        int rq = 0;
+        for (int l = 0; l < nf; ++l) rq = std::max(rq, quads(order[p * 64 + l]));
+        rq = std::max(chunk_quads, (rq + chunk_quads - 1) / chunk_quads * chunk_quads);
+        Matcher mt;
+        mt.n = nf;
+        bool matched = false;
+        for (int attempt = 0; attempt < 2 && !matched; ++attempt) {
+            mt.feas.assign(nf, {});
+            for (int i = 0; i < nf; ++i) {
+                const int m = order[p * 64 + i];
+                const int s4 = first[m] / 4, slack = rq - quads(m);
+                for (int d = 0; d <= slack && d < 16 && s4 - d >= 0; ++d)
+                    mt.feas[i].push_back(((s4 - d) % 16 + 16) % 16);
+                if (attempt == 1) mt.feas[i].resize(1);  // fallback: natural starts, conflicts allowed
+            }
+            for (auto& g : mt.owner) for (int& o : g) o = -1;
+            if (attempt == 0) {
+                std::vector<int> idx(nf);
+                std::iota(idx.begin(), idx.end(), 0);
+                std::stable_sort(idx.begin(), idx.end(),
+                                 [&](int a, int b) { return mt.feas[a].size() < mt.feas[b].size(); });
+                matched = true;
+                for (int i : idx) {
+                    bool seen[4][16] = {};
+                    if (!mt.try_assign(i, seen)) { matched = false; break; }
+                }
+            } else {
+                matched = true;  // handled below: plain lane order
+            }
+        }
+        // lanes
+        bool used_match = false;
+        {
+            int cnt = 0;
+            for (auto& g : mt.owner) for (int o : g) cnt += o >= 0;
+            used_match = cnt == nf;
+        }
+        if (used_match) {
+            for (int g = 0; g < 4; ++g) {
+                int j = 0;
+                for (int r = 0; r < 16; ++r) {
+                    const int i = mt.owner[g][r];
+                    if (i < 0) continue;
+                    const int m = order[p * 64 + i];
+                    const int s4 = first[m] / 4;
+                    const int d = ((s4 - r) % 16 + 16) % 16;
+                    const int lane = kB128Groups[g][j++];
+                    pass_lane_filter[p][lane] = m;
+                    pass_lane_start[p][lane] = 4 * (s4 - d);
+                }
+            }
+        } else {
+            for (int l = 0; l < nf; ++l) {
+                const int m = order[p * 64 + l];
+                pass_lane_filter[p][l] = m;
+                pass_lane_start[p][l] = 4 * (first[m] / 4);
+            }
+        }
+        s.rounds[p] = 4 * rq;
         s.round_off[p] = s.total_rounds;
         s.total_rounds += s.rounds[p];
     }
     s.w.assign((size_t)s.total_rounds * 64, 0.0f);
     for (int p = 0; p < s.n_pass; ++p) {
-        for (int l = 0; l < 64 && p * 64 + l < n_mels; ++l) {
-            const int m = order[p * 64 + l];
+        for (int l = 0; l < 64; ++l) {
+            const int m = pass_lane_filter[p][l];
+            const int st = pass_lane_start[p][l];
             s.filt[p * 64 + l] = m;
-            s.start[p * 64 + l] = first[m];
-            for (int i = 0; i < len[m]; ++i)
-                s.w[(size_t)(s.round_off[p] + i) * 64 + l] = basis[(size_t)m * n_bins + first[m] + i];
-            if (s.rounds[p] > 0) s.max_read = std::max(s.max_read, first[m] + s.rounds[p] - 1);
+            s.start[p * 64 + l] = st;
+            if (m < 0) continue;
+            // quad j of the pass holds bins st + 4j .. st + 4j + 3:
+            //   w[((round_off/4 + j) * 64 + l) * 4 + c]
+            for (int k = first[m]; k <= last[m]; ++k) {
+                const int rel = k - st;
+                s.w[((size_t)(s.round_off[p] / 4 + rel / 4) * 64 + l) * 4 + (rel & 3)] =
+                    basis[(size_t)m * n_bins + k];
+            }
+            s.max_read = std::max(s.max_read, st + s.rounds[p] - 1);
         }
     }
 }

@@ -29,11 +29,14 @@ int64_t num_frames(const Resolved& r, int64_t n_samples);
 
 // Sparse packing of the mel filterbank for the lane-per-filter contraction.
 // Filters are sorted by support length (longest first) and dealt 64 per pass; in pass p lane l
-// owns filter filt[p*64+l] (or -1), reads bins start[p*64+l] + i for i in [0, rounds[p]) and
-// multiplies by w[(round_off[p] + i) * 64 + l] (zero outside the filter's support).
+// owns filter filt[p*64+l] (or -1) and reads bins four at a time: start[p*64+l] is a multiple
+// of 4, quad j covers bins start + 4j .. start + 4j + 3 with weights
+// w[((round_off[p]/4 + j)*64 + l)*4 + c] (zero outside the filter's support).  rounds[p] is the
+// number of bins a lane reads in pass p.  Starts and lanes are chosen so that the 16 lanes the
+// hardware services together read from distinct LDS bank groups.
 struct SparseMel {
     int n_pass = 0;
-    std::vector<int> rounds;     // per pass, a multiple of 4
+    std::vector<int> rounds;     // per pass, a multiple of 4 * chunk_quads
     std::vector<int> round_off;  // per pass, prefix sum of rounds
     std::vector<int32_t> start;  // n_pass * 64
     std::vector<int32_t> filt;   // n_pass * 64
@@ -41,6 +44,7 @@ struct SparseMel {
     int total_rounds = 0;
     int max_read = 0;            // largest bin index any lane reads
 };
-void build_sparse_mel(const std::vector<float>& basis, int n_mels, int n_bins, SparseMel& s);
+// chunk_quads: rounds[p] / 4 is padded to a multiple of this.
+void build_sparse_mel(const std::vector<float>& basis, int n_mels, int n_bins, int chunk_quads, SparseMel& s);
 
 }  // namespace mfcc_host

@@ -53,6 +53,15 @@ class MfccPlan:
         except Exception:
             pass
 
+    def set_profiling(self, enable: bool = True) -> None:
+        _lib.check(_lib.lib().mfcc_plan_set_profiling(self._handle, 1 if enable else 0))
+
+    def last_timings(self):
+        """(front-end kernel ms, dB+DCT kernel ms) of the last execute, from HIP events."""
+        a, b = C.c_float(), C.c_float()
+        _lib.check(_lib.lib().mfcc_plan_last_timings(self._handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     # ------------------------------------------------------------------------------------
     def num_frames(self, n_samples: int) -> int:
         F = _lib.lib().mfcc_num_frames(C.byref(self._cfg_c), int(n_samples))
