@@ -88,11 +88,9 @@ FC_HD void cfft16(float (&re)[16], float (&im)[16]) {
 // y_odd = sum of r[odd n] = (A[0]-A[16])/2 ... expressed through the packed transform as
 // Z[0] = (sum r[2m], sum r[2m+1]).  A[k] = sum_n r[n] exp(-2 pi i n k / 32).
 // The factors of two are absorbed by the caller's twiddle table.
-FC_HD void rdft32(const float (&r)[32], float (&ar)[16], float (&ai)[16]) {
-    float zr[16], zi[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) { zr[m] = r[2 * m]; zi[m] = r[2 * m + 1]; }
-    cfft16(zr, zi);
+// Second half of rdft32: conjugate-symmetric split of Z = cfft16(z), z[m] = r[2m] + i r[2m+1],
+// given in cfft16's output order.
+FC_HD void rdft32_split(const float (&zr)[16], const float (&zi)[16], float (&ar)[16], float (&ai)[16]) {
     ar[0] = zr[cfft16_pos(0)];
     ai[0] = zi[cfft16_pos(0)];
     ar[8] = zr[cfft16_pos(8)];               // A[8] = conj(Z[8])
@@ -107,6 +105,14 @@ FC_HD void rdft32(const float (&r)[32], float (&ar)[16], float (&ai)[16]) {
         ar[k] = er + tr;       ai[k] = ei + ti;      // 2 A[k]
         ar[16 - k] = er - tr;  ai[16 - k] = ti - ei; // 2 A[16-k] = conj(2E - 2 W^k O)
     }
+}
+
+FC_HD void rdft32(const float (&r)[32], float (&ar)[16], float (&ai)[16]) {
+    float zr[16], zi[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { zr[m] = r[2 * m]; zi[m] = r[2 * m + 1]; }
+    cfft16(zr, zi);
+    rdft32_split(zr, zi, ar, ai);
 }
 
 }  // namespace fc

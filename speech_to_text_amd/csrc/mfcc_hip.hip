@@ -20,6 +20,7 @@
 
 #include "../../include/mfcc_hip.h"
 #include "fft_core.h"
+#include "front_2048.h"
 #include "host_tables.h"
 
 namespace {
@@ -41,22 +42,7 @@ int fail(int code, const std::string& msg) {
 // ------------------------------------------------------------------------------------------
 // Ragged batch -> tile table
 // ------------------------------------------------------------------------------------------
-constexpr int TILE_FRAMES = 16;
-
-struct __attribute__((aligned(32))) Tile {
-    int64_t soff;  // first sample of the utterance in d_pcm
-    int64_t row0;  // output row of the tile's first frame
-    int32_t T;     // samples in the utterance
-    int32_t f0;    // first frame of the tile within the utterance
-    int32_t F;     // frames in the utterance
-    int32_t grp;   // top_db group (slot of the running maximum)
-};
-static_assert(sizeof(Tile) == 32, "Tile must be 32 bytes");
-
-struct WsHeader {
-    int32_t n_tiles;
-    int32_t pad[63];
-};
+constexpr int TILE_FRAMES = k2048::TILE_FRAMES;
 
 // One block.  tile_off[u] = number of tiles before utterance u; also zeroes the group maxima.
 __global__ __launch_bounds__(1024) void k_prepare_scan(const int64_t* __restrict__ frame_off,
@@ -113,409 +99,6 @@ __global__ __launch_bounds__(256) void k_prepare_tiles(const int64_t* __restrict
     t.row0 = frame_off[u] + t.f0;
     t.grp = group ? group[u] : u;
     tiles[tile] = t;
-}
-
-// ------------------------------------------------------------------------------------------
-// 2048-point front end: one wavefront per frame
-// ------------------------------------------------------------------------------------------
-// Frame a[n], n = n1 + 64 n2: lane n1 holds the 32 samples n2 = 0..31.
-//  step 1  real 32-point DFT over n2 in registers -> A[n1][k2], k2 = 0..16
-//  twiddle B[n1][k2] = A[n1][k2] W_2048^(n1 k2), k2 = 1..15
-//  exchange through LDS (16 columns of 64 complex; column 0 carries the two real columns
-//          k2 = 0 and 16 as the even/odd-folded real sequence of a 128-point real DFT)
-//  step 2  lane (k2c = lane>>2, q = lane&3) reads column[k2c][16 q + m], m = 0..15 (128
-//          contiguous bytes): 4-point DFT across the quad with DPP (output kb), twiddle
-//          W_64^(m kb), 16-point DFT over m (output ka) -> X[128 ka + 32 kb + k2c];
-//          ka >= 8 are the mirror images of bins 17..31 mod 32
-//  column 0 is post-processed as a 128-point real DFT -> bins 16 j, j = 0..64
-namespace k2048 {
-constexpr int NFFT = 2048;
-constexpr int NBIN = 1025;
-// Exchange column: 64 complex, 2 complex of padding after every 16, stride 72: the
-// ds_write_b64 of step 1 and the ds_read_b128 of step 2 are both bank-conflict free.
-constexpr int COL_STRIDE = 72;
-constexpr int XCH_FLOATS = 16 * COL_STRIDE * 2;   // 2304 floats per wavefront
-constexpr int SPECIAL_OFF = 1152;                 // float offset of the column-0 scratch
-constexpr int SPECIAL_ROW = 24;                   // complex per kb row of that scratch
-constexpr int TW1_FLOATS = 15 * 64 * 2;
-constexpr int W64_STRIDE = 18;                    // complex per kb row (16 + 2 pad)
-constexpr int W64_FLOATS = 4 * W64_STRIDE * 2;
-constexpr int WIN_FLOATS = 2048;
-constexpr int LDS_LIMIT = 160 * 1024;
-constexpr int MAX_MEL_PASS = 4;                   // n_mels <= 256
-constexpr int MEL_CHUNK = 2;                      // ds_read_b128 pairs in flight per batch (mel)
-// LDS bytes of a variant: per-wavefront exchange regions, then tw1, then (optional) w64,
-// window and mel-weight tables.
-constexpr size_t lds_bytes(int waves, bool win_regs, bool w64_regs, int melw_floats) {
-    return sizeof(float) * ((size_t)waves * XCH_FLOATS + TW1_FLOATS + (w64_regs ? 0 : W64_FLOATS) +
-                            (win_regs ? 0 : WIN_FLOATS) + (size_t)melw_floats);
-}
-}  // namespace k2048
-
-struct MelPass {
-    int32_t rounds;      // bins each lane reads in this pass (multiple of 4 * MEL_CHUNK)
-    int32_t round_off;   // first round of this pass in the weight table
-};
-
-struct FrontArgs {
-    const float* pcm;
-    const Tile* tiles;
-    const WsHeader* hdr;
-    const float* window;     // 2048
-    const float2* tw1;       // 15 x 64, scaled
-    const float2* w64;       // 4 x 16
-    const float2* tw128;     // 64
-    const float4* melw;      // (total_rounds / 4) x 64 quads of weights
-    const int32_t* mel_start;  // bin index (multiple of 4) each lane starts reading at
-    const int32_t* mel_filt;
-    const MelPass* mel_pass;
-    float* mel_out;          // (rows, n_mels) or nullptr
-    float* spec_out;         // (rows, 1025) or nullptr
-    uint32_t* gmax;
-    int32_t n_pass;
-    int32_t n_mels;
-    int32_t total_rounds;
-    int32_t hop;
-    int32_t pad;             // n_fft/2 if center else 0
-    int32_t reflect;
-    int32_t pw_mode;         // 0: power 2, 1: power 1, 2: general
-    int32_t ablate;          // development only: bit 0 skips the mel stage
-    float half_power;        // power / 2
-};
-
-__device__ __forceinline__ float quad_swap2(float v) {  // lane i <- lane i^2 within its quad
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E,
-                                                              0xF, 0xF, true));
-}
-__device__ __forceinline__ float quad_swap1(float v) {  // lane i <- lane i^1
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1,
-                                                              0xF, 0xF, true));
-}
-
-// |X|^power from |X|^2.  PW = 0: power 2 (the reference's); PW = 1: any other power, decided at
-// run time (kept out of the power-2 instantiations: powf is ~200 instructions per call site).
-template <int PW>
-__device__ __forceinline__ float apply_power(float mag2, int pw_mode, float half_power) {
-    if (PW == 0) return mag2;
-    return pw_mode == 1 ? sqrtf(mag2) : powf(mag2, half_power);
-}
-
-__device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t T) {
-    if (T <= 1) return 0;
-    const int64_t period = 2 * (T - 1);
-    int64_t m = i % period;
-    if (m < 0) m += period;
-    return m < T ? m : period - m;
-}
-
-__device__ __forceinline__ void flush_max(float runmax, int grp, uint32_t* gmax, int lane) {
-    if (grp < 0) return;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) runmax = fmaxf(runmax, __shfl_xor(runmax, o));
-    if (lane == 0 && runmax > 0.0f) atomicMax(&gmax[grp], __float_as_uint(runmax));
-}
-
-// Edge frames (those that overlap the zero / reflect padding) are rare: stage them through the
-// wavefront's LDS region with a rolled loop so the hot path stays small.
-__device__ __noinline__ void stage_edge_frame(float* X, const float* p, int start, int T, int reflect,
-                                              int lane) {
-#pragma unroll 1
-    for (int n2 = 0; n2 < 32; ++n2) {
-        const int idx = start + lane + 64 * n2;
-        float v = 0.0f;
-        if (reflect) {
-            if (T > 0) v = p[reflect_index(idx, T)];
-        } else if (idx >= 0 && idx < T) {
-            v = p[idx];
-        }
-        X[lane + 64 * n2] = v;
-    }
-}
-
-template <int WAVES, bool WIN_REGS, bool W64_REGS, bool MELW_LDS, int PW>
-__global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) {
-    using namespace k2048;
-    constexpr int THREADS = WAVES * 64;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* X = lds + wave * XCH_FLOATS;
-    float2* X2 = reinterpret_cast<float2*>(X);
-    float* tab = lds + WAVES * XCH_FLOATS;
-    float2* tw1_l = reinterpret_cast<float2*>(tab);
-    tab += TW1_FLOATS;
-    float2* w64_l = reinterpret_cast<float2*>(tab);
-    if (!W64_REGS) tab += W64_FLOATS;
-    float* win_l = tab;
-    if (!WIN_REGS) tab += WIN_FLOATS;
-    float4* melw_l = reinterpret_cast<float4*>(tab);
-
-    for (int i = tid; i < WAVES * XCH_FLOATS; i += THREADS) lds[i] = 0.0f;
-    for (int i = tid; i < 15 * 64; i += THREADS) tw1_l[i] = a.tw1[i];
-    if (!W64_REGS) { if (tid < 64) w64_l[(tid >> 4) * W64_STRIDE + (tid & 15)] = a.w64[tid]; }
-    if (!WIN_REGS) { for (int i = tid; i < 2048; i += THREADS) win_l[i] = a.window[i]; }
-    if (MELW_LDS) { for (int i = tid; i < a.total_rounds * 16; i += THREADS) melw_l[i] = a.melw[i]; }
-    __syncthreads();
-
-    const int q = lane & 3, k2c = lane >> 2;
-    const int kb = ((q & 1) << 1) | (q >> 1);       // the quad DFT leaves output kb in lane q
-    float win[WIN_REGS ? 32 : 1];
-    if (WIN_REGS) {
-#pragma unroll
-        for (int n2 = 0; n2 < 32; ++n2) win[n2] = a.window[lane + 64 * n2];
-    }
-    float2 w64r[W64_REGS ? 16 : 1];
-    if (W64_REGS) {
-#pragma unroll
-        for (int m = 0; m < 16; ++m) w64r[m] = a.w64[kb * 16 + m];
-    }
-    const float2 tw128 = a.tw128[lane];
-
-    const float sgn1 = (q & 2) ? -1.0f : 1.0f;
-    const float sgn2 = (q & 1) ? -1.0f : 1.0f;
-    const bool lane3 = (q == 3);
-    // exchange addressing (complex index c of column k2 lives at k2 * 72 + c + 2 * (c >> 4))
-    const int xw_off = lane + 2 * (lane >> 4);                  // step-1 write, + k2 * COL_STRIDE
-    const int y_off = lane + 4 * (lane >> 5);                   // column 0 as 128 reals
-    const int xr_off = k2c * COL_STRIDE + 18 * q;               // step-2 read (complex index)
-    // power spectrum addressing: ka < 8 -> bin 128 ka + pb0; ka >= 8 -> bin 128 (15 - ka) + pb1
-    const int pb0 = 32 * kb + k2c;
-    const int pb1 = 128 - 32 * kb - k2c;
-    // column-0 scratch: C[j] at (j & 3) * SPECIAL_ROW + (j >> 2)
-    const int sj = (lane & 3) * SPECIAL_ROW + (lane >> 2);
-    const int sm = (((64 - lane) & 63) & 3) * SPECIAL_ROW + (((64 - lane) & 63) >> 2);
-
-    // per-lane mel work, loop-invariant: first bin, filter index; per pass: rounds, weight offset
-    int mel_st[MAX_MEL_PASS], mel_fi[MAX_MEL_PASS], mel_rounds[MAX_MEL_PASS], mel_roff[MAX_MEL_PASS];
-#pragma unroll
-    for (int p = 0; p < MAX_MEL_PASS; ++p) {
-        mel_st[p] = 0; mel_fi[p] = -1; mel_rounds[p] = 0; mel_roff[p] = 0;
-        if (p < a.n_pass) {
-            mel_st[p] = a.mel_start[p * 64 + lane];
-            mel_fi[p] = a.mel_filt[p * 64 + lane];
-            mel_rounds[p] = a.mel_pass[p].rounds;
-            mel_roff[p] = a.mel_pass[p].round_off;
-        }
-    }
-
-    float runmax = 0.0f;
-    int cur_grp = -1;
-    const int n_tiles = a.hdr->n_tiles;
-
-    // Work unit = one frame slot (tile, frame-in-tile); consecutive wavefronts take consecutive
-    // frames so that the 75 % sample overlap between neighbouring frames is served by L1/L2.
-    // The raw samples of the NEXT frame are requested before the current one is transformed
-    // (software pipelining: the wavefront never waits on HBM latency with nothing to do).
-    // Each workgroup owns one contiguous block of slots and its wavefronts interleave inside it,
-    // so a wavefront stays within one utterance for many frames (one atomicMax per utterance
-    // change, not per frame).
-    const int64_t n_slots = (int64_t)n_tiles * TILE_FRAMES;
-    const int64_t slot_stride = WAVES;
-    const int64_t per_wg = ((n_slots + gridDim.x - 1) / gridDim.x + WAVES - 1) / WAVES * WAVES;
-    const int64_t slot_end = min(n_slots, (int64_t)(blockIdx.x + 1) * per_wg);
-
-    Tile ti;           // current work
-    int t = 0;
-    bool have = false, interior = false;
-    int64_t slot = (int64_t)blockIdx.x * per_wg + wave;
-    float r[32];
-
-    // find the first valid slot at or after `s`; wave-uniform
-    auto next_valid = [&](int64_t s, Tile& o_ti, int& o_t, int64_t& o_slot) -> bool {
-        for (; s < slot_end; s += slot_stride) {
-            const Tile c = a.tiles[s >> 4];
-            const int tt = c.f0 + (int)(s & 15);
-            if (tt < c.F) { o_ti = c; o_t = tt; o_slot = s; return true; }
-        }
-        return false;
-    };
-    auto is_interior = [&](const Tile& c, int tt) -> bool {
-        const int start = tt * a.hop - a.pad;
-        return start >= 0 && start + NFFT <= c.T;
-    };
-
-    have = next_valid(slot, ti, t, slot);
-    if (have) {
-        interior = is_interior(ti, t);
-        if (interior) {
-            const float* pp = a.pcm + ti.soff + (t * a.hop - a.pad) + lane;
-#pragma unroll
-            for (int n2 = 0; n2 < 32; ++n2) r[n2] = pp[64 * n2];
-        }
-    }
-
-    while (have) {
-        if (ti.grp != cur_grp) {
-            flush_max(runmax, cur_grp, a.gmax, lane);
-            cur_grp = ti.grp;
-            runmax = 0.0f;
-        }
-        const int64_t row = ti.row0 + (t - ti.f0);
-
-        // ---- request the next frame's samples ------------------------------------------------
-        Tile ti_n;
-        int t_n = 0;
-        int64_t slot_n = 0;
-        bool interior_n = false;
-        float rn[32];
-        const bool have_n = next_valid(slot + slot_stride, ti_n, t_n, slot_n);
-        if (have_n) {
-            interior_n = is_interior(ti_n, t_n);
-            if (interior_n) {
-                const float* pp = a.pcm + ti_n.soff + (t_n * a.hop - a.pad) + lane;
-#pragma unroll
-                for (int n2 = 0; n2 < 32; ++n2) rn[n2] = pp[64 * n2];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of this frame's work
-
-        // ---- edge frames come through LDS; then window -------------------------------------------
-        if (!interior) {
-            stage_edge_frame(X, a.pcm + ti.soff, t * a.hop - a.pad, ti.T, a.reflect, lane);
-#pragma unroll
-            for (int n2 = 0; n2 < 32; ++n2) r[n2] = X[lane + 64 * n2];
-        }
-        if (WIN_REGS) {
-#pragma unroll
-            for (int n2 = 0; n2 < 32; ++n2) r[n2] *= win[n2];
-        } else {
-            float wv[32];
-#pragma unroll
-            for (int n2 = 0; n2 < 32; ++n2) wv[n2] = win_l[lane + 64 * n2];
-            __builtin_amdgcn_sched_barrier(0);   // all LDS reads in flight before the first use
-#pragma unroll
-            for (int n2 = 0; n2 < 32; ++n2) r[n2] *= wv[n2];
-        }
-
-        // ---- step 1: real DFT-32 over n2, twiddle, exchange ------------------------------
-        {
-            float2 tw[16];
-#pragma unroll
-            for (int k2 = 1; k2 < 16; ++k2) tw[k2] = tw1_l[(k2 - 1) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);   // twiddle reads overlap the in-register DFT
-            float ar[16], ai[16];
-            fc::rdft32(r, ar, ai);
-            X[y_off] = ar[0];                    // y[n1]      = sum over even n2
-            X[72 + y_off] = ai[0];               // y[64 + n1] = sum over odd n2 (complex index 32 + ...)
-#pragma unroll
-            for (int k2 = 1; k2 < 16; ++k2) {
-                fc::cmul(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
-                X2[k2 * COL_STRIDE + xw_off] = make_float2(ar[k2], ai[k2]);
-            }
-        }
-
-        // ---- step 2: quad DFT-4 (DPP), twiddle, DFT-16 over m -------------------------------
-        float dr[16], di[16];
-        {
-            float2 w6[16];
-            const float4* src = reinterpret_cast<const float4*>(X2 + xr_off);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float4 v = src[j];
-                dr[2 * j] = v.x; di[2 * j] = v.y; dr[2 * j + 1] = v.z; di[2 * j + 1] = v.w;
-            }
-            if (W64_REGS) {
-#pragma unroll
-                for (int m = 1; m < 16; ++m) w6[m] = w64r[m];
-            } else {
-                const float4* wsrc = reinterpret_cast<const float4*>(w64_l + kb * W64_STRIDE);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float4 v = wsrc[j];
-                    w6[2 * j] = make_float2(v.x, v.y); w6[2 * j + 1] = make_float2(v.z, v.w);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);   // all exchange + twiddle reads in flight
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float xr = fmaf(sgn1, dr[i], quad_swap2(dr[i]));
-                float xi = fmaf(sgn1, di[i], quad_swap2(di[i]));
-                const float yr = lane3 ? xi : xr;       // lane 3: multiply by -i
-                const float yi = lane3 ? -xr : xi;
-                dr[i] = fmaf(sgn2, yr, quad_swap1(yr));
-                di[i] = fmaf(sgn2, yi, quad_swap1(yi));
-            }
-#pragma unroll
-            for (int m = 1; m < 16; ++m) fc::cmul(dr[m], di[m], w6[m].x, w6[m].y);
-            fc::cfft16(dr, di);
-        }
-
-        // ---- power spectrum -> LDS (natural bin order) -------------------------------------
-        // All exchange reads of this wavefront are complete (data dependence above), so the
-        // exchange region can be overwritten.
-        if (lane < 4) {
-            float2* S = reinterpret_cast<float2*>(X + SPECIAL_OFF) + kb * SPECIAL_ROW;
-#pragma unroll
-            for (int ka = 0; ka < 16; ++ka)
-                S[ka] = make_float2(dr[fc::cfft16_pos(ka)], di[fc::cfft16_pos(ka)]);
-        } else {
-#pragma unroll
-            for (int ka = 0; ka < 16; ++ka) {
-                const float re = dr[fc::cfft16_pos(ka)], im = di[fc::cfft16_pos(ka)];
-                const float pw = apply_power<PW>(re * re + im * im, a.pw_mode, a.half_power);
-                if (ka < 8) X[pb0 + 128 * ka] = pw; else X[pb1 + 128 * (15 - ka)] = pw;
-            }
-        }
-        {
-            // column 0: C = DFT-64 of c[r] = y[2r] + i y[2r+1]; Y[j] = E[j] + W_128^j O[j]
-            const float2* S = reinterpret_cast<const float2*>(X + SPECIAL_OFF);
-            const float2 cj = S[sj];
-            const float2 cm = S[sm];
-            const float er = cj.x + cm.x, ei = cj.y - cm.y;   // 2 E[j]
-            float tr = cj.y + cm.y, ti_ = cm.x - cj.x;        // 2 O[j] = -i (C[j] - conj C[64-j])
-            fc::cmul(tr, ti_, tw128.x, tw128.y);
-            const float yr = er + tr, yi = ei + ti_;          // 2 Y[j]
-            X[16 * lane] = apply_power<PW>(0.25f * (yr * yr + yi * yi), a.pw_mode, a.half_power);
-            if (lane == 0) {
-                const float zr = er - tr, zi = ei - ti_;      // 2 Y[64] (real)
-                X[1024] = apply_power<PW>(0.25f * (zr * zr + zi * zi), a.pw_mode, a.half_power);
-            }
-        }
-
-        if (a.spec_out) {
-            float* so = a.spec_out + row * NBIN;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) so[i * 64 + lane] = X[i * 64 + lane];
-            if (lane == 0) so[1024] = X[1024];
-        }
-
-        // ---- sparse mel filterbank: lane = filter, two bins per round ----------------------
-        if (a.mel_out && !(a.ablate & 1)) {
-            float* mo = a.mel_out + row * a.n_mels;
-#pragma unroll
-            for (int p = 0; p < MAX_MEL_PASS; ++p) {
-                if (p < a.n_pass) {
-                    const float4* wp = (MELW_LDS ? melw_l : a.melw) + (mel_roff[p] >> 2) * 64 + lane;
-                    const float4* pp = reinterpret_cast<const float4*>(X + mel_st[p]);
-                    float acc0 = 0.0f, acc1 = 0.0f;
-                    for (int i = 0; i < (mel_rounds[p] >> 2); i += MEL_CHUNK) {
-                        float4 w[MEL_CHUNK], v[MEL_CHUNK];
-#pragma unroll
-                        for (int j = 0; j < MEL_CHUNK; ++j) { w[j] = wp[(i + j) * 64]; v[j] = pp[i + j]; }
-                        __builtin_amdgcn_sched_barrier(0);   // 2 * MEL_CHUNK reads in flight
-#pragma unroll
-                        for (int j = 0; j < MEL_CHUNK; ++j) {
-                            acc0 = fmaf(w[j].x, v[j].x, acc0);
-                            acc1 = fmaf(w[j].y, v[j].y, acc1);
-                            acc0 = fmaf(w[j].z, v[j].z, acc0);
-                            acc1 = fmaf(w[j].w, v[j].w, acc1);
-                        }
-                    }
-                    const float acc = acc0 + acc1;
-                    if (mel_fi[p] >= 0) {
-                        mo[mel_fi[p]] = acc;
-                        runmax = fmaxf(runmax, acc);
-                    }
-                }
-            }
-        }
-
-        have = have_n; ti = ti_n; t = t_n; slot = slot_n; interior = interior_n;
-#pragma unroll
-        for (int n2 = 0; n2 < 32; ++n2) r[n2] = rn[n2];
-    }
-    flush_max(runmax, cur_grp, a.gmax, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -689,7 +272,8 @@ WsLayout ws_layout(int64_t total_frames, int32_t n_utts, int n_mels, bool need_m
 struct FrontVariant {
     void (*fn)(const FrontArgs);
     int waves;
-    bool win_regs, w64_regs, melw_lds;
+    int win, tw1;            // k2048::TableHome
+    bool w64_regs, melw_lds;
 };
 
 struct mfcc_plan {
@@ -723,21 +307,32 @@ namespace {
 
 // Front-end kernel variants: wavefronts per workgroup (one workgroup per CU; LDS-limited) and
 // where the per-lane constant tables live.  MFCC_HIP_VARIANT selects one for experiments.
+#define FRONT_VARIANT(W, WIN, TW1, W64R, MELW, PF, PW) \
+    {k_melspec_2048<W, WIN, TW1, W64R, MELW, PF, PW>, W, WIN, TW1, W64R, MELW}
+using k2048::IN_GLOBAL;
+using k2048::IN_LDS;
+using k2048::IN_REGS;
 const FrontVariant kFrontVariants[] = {
-    {k_melspec_2048<12, false, false, false, 0>, 12, false, false, false},
-    {k_melspec_2048<12, true, true, true, 0>, 12, true, true, true},
-    {k_melspec_2048<12, false, false, true, 0>, 12, false, false, true},
-    {k_melspec_2048<12, true, false, true, 0>, 12, true, false, true},
-    {k_melspec_2048<8, true, true, true, 0>, 8, true, true, true},
-    {k_melspec_2048<8, false, false, true, 0>, 8, false, false, true},
+    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, false, true, 0),   // 0: fallback, mel weights streamed
+    FRONT_VARIANT(12, IN_REGS, IN_LDS, true, true, true, 0),    // 1
+    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, true, true, 0),    // 2
+    FRONT_VARIANT(12, IN_REGS, IN_LDS, false, true, true, 0),   // 3
+    FRONT_VARIANT(8, IN_REGS, IN_LDS, true, true, true, 0),     // 4
+    FRONT_VARIANT(8, IN_LDS, IN_LDS, false, true, true, 0),     // 5
+    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, true, false, 0),   // 6: no prefetch
+    FRONT_VARIANT(14, IN_LDS, IN_LDS, false, true, false, 0),   // 7
+    FRONT_VARIANT(14, IN_GLOBAL, IN_GLOBAL, false, true, false, 0),  // 8
+    FRONT_VARIANT(15, IN_GLOBAL, IN_GLOBAL, false, true, false, 0),  // 9
+    FRONT_VARIANT(16, IN_GLOBAL, IN_GLOBAL, false, false, false, 0), // 10
+    FRONT_VARIANT(12, IN_GLOBAL, IN_LDS, false, true, true, 0),      // 11
 };
 // power != 2: same structure as variants 0 (mel weights streamed) and 2 (mel weights in LDS).
 const FrontVariant kFrontGeneralPower[] = {
-    {k_melspec_2048<12, false, false, false, 1>, 12, false, false, false},
-    {k_melspec_2048<12, false, false, true, 1>, 12, false, false, true},
+    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, false, true, 1),
+    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, true, true, 1),
 };
 constexpr int kNumFrontVariants = sizeof(kFrontVariants) / sizeof(kFrontVariants[0]);
-constexpr int kDefaultFrontVariant = 2;
+constexpr int kDefaultFrontVariant = 6;
 
 int select_variant(mfcc_plan* p) {
     int v = kDefaultFrontVariant;
@@ -746,14 +341,14 @@ int select_variant(mfcc_plan* p) {
     const int melw_floats = p->sm.total_rounds * 64;
     auto bytes = [&](int i) {
         const FrontVariant& f = kFrontVariants[i];
-        return k2048::lds_bytes(f.waves, f.win_regs, f.w64_regs, f.melw_lds ? melw_floats : 0);
+        return k2048::lds_bytes(f.waves, f.win, f.tw1, f.w64_regs, f.melw_lds ? melw_floats : 0);
     };
     if (bytes(v) > (size_t)k2048::LDS_LIMIT) v = 0;  // mel weights too large for LDS: stream them
     if (bytes(v) > (size_t)k2048::LDS_LIMIT) return fail(MFCC_E_UNSUPPORTED, "LDS budget exceeded");
     p->front = kFrontVariants[v];
     if (p->r.c.power != 2.0f) p->front = kFrontGeneralPower[p->front.melw_lds ? 1 : 0];
     p->variant = v;
-    p->front_lds_bytes = k2048::lds_bytes(p->front.waves, p->front.win_regs, p->front.w64_regs,
+    p->front_lds_bytes = k2048::lds_bytes(p->front.waves, p->front.win, p->front.tw1, p->front.w64_regs,
                                          p->front.melw_lds ? melw_floats : 0);
     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(p->front.fn),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
