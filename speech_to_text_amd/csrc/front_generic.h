@@ -1,0 +1,184 @@
+// Generic front end for gfx950: any even n_fft that fits LDS, as a dense DFT on the matrix cores.
+//
+//   pad / frame / window -> DFT as an fp32 MFMA GEMM -> |X|^power -> sparse mel filterbank
+//
+// Used for every n_fft other than 2048 (e.g. the 400-point and 512-point ASR front ends), where
+// the DFT matrix is a genuine dense contraction: [16 frames x n_fft] . [n_fft x 2 n_bins] with
+// v_mfma_f32_16x16x4_f32.  Same role as front_2048.h: the stft + abs**power + mel einsum part of
+// librosa.feature.mfcc (/root/reference/src/preprocess.py:134) for non-default n_fft.
+//
+// One workgroup (4 wavefronts) per 16-frame tile:
+//   stage   each wavefront windows 4 frames into LDS A[16][lda]
+//   DFT     wavefront w takes column tiles w, w+4, ...; columns interleave (cos, -sin) so a bin's
+//           real and imaginary parts sit in neighbouring lanes; power by one DPP swap
+//   mel     wavefront w runs the lane-per-filter contraction on frames 4w .. 4w+3 from LDS P
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "front_2048.h"
+
+struct GenArgs {
+    const float* pcm;
+    const Tile* tiles;
+    const WsHeader* hdr;
+    const float* window;       // n_fft
+    const float* dfrag;        // [col tile][k step][lane] DFT matrix in MFMA B-fragment order
+    const float4* melw;
+    const int32_t* mel_start;
+    const int32_t* mel_filt;
+    const MelPass* mel_pass;
+    float* mel_out;
+    float* spec_out;
+    uint32_t* gmax;
+    int32_t n_pass;
+    int32_t n_mels;
+    int32_t n_fft;
+    int32_t n_bins;
+    int32_t kpad;              // n_fft rounded up to a multiple of 4
+    int32_t n_coltiles;        // ceil(2 n_bins / 16)
+    int32_t lda;               // floats per staged frame row (kpad + 4)
+    int32_t ldp;               // floats per power-spectrum row (multiple of 4, + slack for mel over-read)
+    int32_t hop;
+    int32_t pad;
+    int32_t reflect;
+    int32_t pw_mode;
+    float half_power;
+};
+
+typedef float gen_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int PW>
+__global__ __launch_bounds__(256) void k_melspec_generic(const GenArgs a) {
+    using namespace k2048;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* A = lds;                       // 16 x lda
+    float* P = lds + 16 * a.lda;          // 16 x ldp
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_tiles = a.hdr->n_tiles;
+    const int per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const int tile_end = min(n_tiles, (int)(blockIdx.x + 1) * per_wg);
+
+    int mel_st[MAX_MEL_PASS], mel_fi[MAX_MEL_PASS], mel_rounds[MAX_MEL_PASS], mel_roff[MAX_MEL_PASS];
+#pragma unroll
+    for (int p = 0; p < MAX_MEL_PASS; ++p) {
+        mel_st[p] = 0; mel_fi[p] = -1; mel_rounds[p] = 0; mel_roff[p] = 0;
+        if (p < a.n_pass) {
+            mel_st[p] = a.mel_start[p * 64 + lane];
+            mel_fi[p] = a.mel_filt[p * 64 + lane];
+            mel_rounds[p] = __builtin_amdgcn_readfirstlane(a.mel_pass[p].rounds);
+            mel_roff[p] = __builtin_amdgcn_readfirstlane(a.mel_pass[p].round_off);
+        }
+    }
+    // zero the power rows once: the slack past n_bins is read (with zero weights) by the mel stage
+    for (int i = threadIdx.x; i < 16 * a.ldp; i += 256) P[i] = 0.0f;
+
+    float runmax = 0.0f;
+    int cur_grp = -1;
+
+    for (int tile = blockIdx.x * per_wg; tile < tile_end; ++tile) {
+        const Tile ti = a.tiles[tile];
+        const int nvalid = min(TILE_FRAMES, ti.F - ti.f0);
+        if (ti.grp != cur_grp) {
+            flush_max(runmax, cur_grp, a.gmax, lane);
+            cur_grp = ti.grp;
+            runmax = 0.0f;
+        }
+        __syncthreads();   // previous tile's mel stage is done with P, its DFT with A
+
+        // ---- stage: pad + frame + window ------------------------------------------------------
+        const float* p = a.pcm + ti.soff;
+        for (int fi = 0; fi < 4; ++fi) {
+            const int f = 4 * wave + fi;
+            float* rowp = A + f * a.lda;
+            const int start = (ti.f0 + f) * a.hop - a.pad;
+            for (int n = lane; n < a.lda; n += 64) {
+                float v = 0.0f;
+                if (f < nvalid && n < a.n_fft) {
+                    const int idx = start + n;
+                    if (a.reflect) {
+                        if (ti.T > 0) v = p[reflect_index(idx, ti.T)];
+                    } else if (idx >= 0 && idx < ti.T) {
+                        v = p[idx];
+                    }
+                    v *= a.window[n];
+                }
+                rowp[n] = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- DFT on the matrix cores, power, -> P ------------------------------------------------
+        const float* arow = A + (lane & 15) * a.lda + (lane >> 4);
+        const int ksteps = a.kpad >> 2;
+        for (int ct = wave; ct < a.n_coltiles; ct += 4) {
+            const float* frag = a.dfrag + (size_t)ct * ksteps * 64 + lane;
+            gen_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            int s = 0;
+            for (; s + 8 <= ksteps; s += 8) {
+                float av[8], bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { av[j] = arow[4 * (s + j)]; bv[j] = frag[(size_t)(s + j) * 64]; }
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j + 1], bv[j + 1], acc1, 0, 0, 0);
+                }
+            }
+            for (; s < ksteps; ++s)
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * s], frag[(size_t)s * 64], acc0, 0, 0, 0);
+            // acc[i]: frame 4 (lane >> 4) + i, column 16 ct + (lane & 15); even column = Re, odd = Im
+            const int col = 16 * ct + (lane & 15);
+            const int bin = col >> 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float c = acc0[i] + acc1[i];
+                float v = c * c;
+                v += quad_swap1(v);
+                if (!(lane & 1) && bin < a.n_bins)
+                    P[(4 * (lane >> 4) + i) * a.ldp + bin] = apply_power<PW>(v, a.pw_mode, a.half_power);
+            }
+        }
+        __syncthreads();
+
+        // ---- per frame: optional spectrogram tap, sparse mel -----------------------------------
+        for (int fi = 0; fi < 4; ++fi) {
+            const int f = 4 * wave + fi;
+            if (f >= nvalid) break;
+            const float* X = P + f * a.ldp;
+            const int64_t row = ti.row0 + f;
+            if (a.spec_out) {
+                float* so = a.spec_out + row * a.n_bins;
+                for (int k = lane; k < a.n_bins; k += 64) so[k] = X[k];
+            }
+            if (a.mel_out) {
+                float* mo = a.mel_out + row * a.n_mels;
+#pragma unroll
+                for (int pp_ = 0; pp_ < MAX_MEL_PASS; ++pp_) {
+                    if (pp_ < a.n_pass) {
+                        const float4* wp = a.melw + (mel_roff[pp_] >> 2) * 64 + lane;
+                        const float4* xp = reinterpret_cast<const float4*>(X + mel_st[pp_]);
+                        float acc0 = 0.0f, acc1 = 0.0f;
+                        const int nq = mel_rounds[pp_] >> 2;
+                        for (int i = 0; i < nq; ++i) {
+                            const float4 w = wp[i * 64];
+                            const float4 v = xp[i];
+                            acc0 = fmaf(w.x, v.x, acc0);
+                            acc1 = fmaf(w.y, v.y, acc1);
+                            acc0 = fmaf(w.z, v.z, acc0);
+                            acc1 = fmaf(w.w, v.w, acc1);
+                        }
+                        const float acc = acc0 + acc1;
+                        if (mel_fi[pp_] >= 0) {
+                            mo[mel_fi[pp_]] = acc;
+                            runmax = fmaxf(runmax, acc);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    flush_max(runmax, cur_grp, a.gmax, lane);
+}

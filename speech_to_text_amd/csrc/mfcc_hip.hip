@@ -21,6 +21,7 @@
 #include "../../include/mfcc_hip.h"
 #include "fft_core.h"
 #include "front_2048.h"
+#include "front_generic.h"
 #include "host_tables.h"
 
 namespace {
@@ -298,6 +299,10 @@ struct mfcc_plan {
     MelPass* d_mel_pass = nullptr;
     float* d_dct_frag = nullptr;
     float* d_lifter = nullptr;
+    float* d_dfrag = nullptr;
+    // generic (dense DFT) front end geometry
+    int g_kpad = 0, g_lda = 0, g_ldp = 0, g_coltiles = 0;
+    size_t g_lds_bytes = 0;
     // optional per-kernel timing (mfcc_plan_set_profiling)
     bool profiling = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // before front, after front, after dB+DCT
@@ -353,6 +358,14 @@ int select_variant(mfcc_plan* p) {
     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(p->front.fn),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)p->front_lds_bytes);
+    if (e2 != hipSuccess) return fail(MFCC_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e2));
+    return MFCC_OK;
+}
+
+int setup_generic(mfcc_plan* p) {
+    const void* fn = p->r.c.power == 2.0f ? reinterpret_cast<const void*>(k_melspec_generic<0>)
+                                          : reinterpret_cast<const void*>(k_melspec_generic<1>);
+    hipError_t e2 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->g_lds_bytes);
     if (e2 != hipSuccess) return fail(MFCC_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e2));
     return MFCC_OK;
 }
@@ -447,15 +460,12 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
     mfcc_host::Resolved r;
     const std::string e = mfcc_host::resolve(cfg, &r);
     if (!e.empty()) return fail(MFCC_E_INVALID, e);
-    if (r.c.n_fft != k2048::NFFT)
-        return fail(MFCC_E_UNSUPPORTED, "this build has kernels for n_fft = 2048 only");
-
     mfcc_plan* p = new (std::nothrow) mfcc_plan();
     if (!p) return fail(MFCC_E_NOMEM, "out of host memory");
     p->r = r;
     p->r.c.window = nullptr;      // the copies below are what the plan keeps
     p->r.c.mel_basis = nullptr;
-    p->fast2048 = true;
+    p->fast2048 = (r.c.n_fft == k2048::NFFT);
 
     hipError_t he = hipGetDevice(&p->device);
     hipDeviceProp_t prop;
@@ -495,9 +505,35 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         delete p;
         return fail(MFCC_E_UNSUPPORTED, "n_mels > 256 is not supported");
     }
-    if (p->sm.max_read >= k2048::XCH_FLOATS) {
+    if (p->fast2048 && p->sm.max_read >= k2048::XCH_FLOATS) {
         delete p;
         return fail(MFCC_E_UNSUPPORTED, "mel filter support too wide for the LDS staging region");
+    }
+    std::vector<float> dfrag;
+    if (!p->fast2048) {
+        // Dense DFT matrix [n_fft x 2 n_bins], columns interleaved (cos, -sin), in the B-fragment
+        // order of v_mfma_f32_16x16x4_f32: lane l supplies B[k = l >> 4][j = l & 15].
+        const int N = r.c.n_fft;
+        p->g_kpad = (N + 3) / 4 * 4;
+        p->g_lda = p->g_kpad + 4;
+        p->g_ldp = (std::max(r.n_bins, p->sm.max_read + 1) + 3) / 4 * 4;
+        p->g_coltiles = (2 * r.n_bins + 15) / 16;
+        p->g_lds_bytes = sizeof(float) * 16 * ((size_t)p->g_lda + p->g_ldp);
+        if (p->g_lds_bytes > (size_t)k2048::LDS_LIMIT) {
+            delete p;
+            return fail(MFCC_E_UNSUPPORTED, "n_fft too large for the generic (dense DFT) kernel; "
+                                            "supported: n_fft = 2048, or even n_fft up to about 1600");
+        }
+        const int ksteps = p->g_kpad / 4;
+        dfrag.assign((size_t)p->g_coltiles * ksteps * 64, 0.0f);
+        for (int ct = 0; ct < p->g_coltiles; ++ct)
+            for (int s = 0; s < ksteps; ++s)
+                for (int l = 0; l < 64; ++l) {
+                    const int n = 4 * s + (l >> 4), col = 16 * ct + (l & 15), bin = col >> 1;
+                    if (n >= N || bin >= r.n_bins) continue;
+                    const double ang = 2.0 * PI * (double)(((int64_t)n * bin) % N) / (double)N;
+                    dfrag[((size_t)ct * ksteps + s) * 64 + l] = (float)((col & 1) ? -std::sin(ang) : std::cos(ang));
+                }
     }
     std::vector<MelPass> passes(p->sm.n_pass);
     for (int i = 0; i < p->sm.n_pass; ++i) passes[i] = MelPass{p->sm.rounds[i], p->sm.round_off[i]};
@@ -535,7 +571,8 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
     if (rc == MFCC_OK) rc = upload(passes, &p->d_mel_pass);
     if (rc == MFCC_OK) rc = upload(frag, &p->d_dct_frag);
     if (rc == MFCC_OK) rc = upload(lifter, &p->d_lifter);
-    if (rc == MFCC_OK) rc = select_variant(p);
+    if (rc == MFCC_OK) rc = upload(dfrag, &p->d_dfrag);
+    if (rc == MFCC_OK) rc = p->fast2048 ? select_variant(p) : setup_generic(p);
     if (rc != MFCC_OK) {
         const std::string keep = g_err;
         mfcc_plan_destroy(p);
@@ -551,7 +588,7 @@ void mfcc_plan_destroy(mfcc_plan* p) {
     (void)hipFree(p->d_window); (void)hipFree(p->d_tw1); (void)hipFree(p->d_w64);
     (void)hipFree(p->d_tw128); (void)hipFree(p->d_melw); (void)hipFree(p->d_mel_start);
     (void)hipFree(p->d_mel_filt); (void)hipFree(p->d_mel_pass); (void)hipFree(p->d_dct_frag);
-    (void)hipFree(p->d_lifter);
+    (void)hipFree(p->d_lifter); (void)hipFree(p->d_dfrag);
     for (int i = 0; i < 3; ++i) if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
     delete p;
 }
@@ -576,6 +613,32 @@ static int launch_front(const mfcc_plan* plan, const float* d_pcm, const int64_t
     hipLaunchKernelGGL(k_prepare_tiles, dim3(pt_blocks), dim3(256), 0, st, d_sample_offsets,
                        d_frame_offsets, d_group, tile_off, n_utts, tiles);
 
+    if (!plan->fast2048) {
+        GenArgs ga;
+        ga.pcm = d_pcm; ga.tiles = tiles; ga.hdr = hdr;
+        ga.window = plan->d_window; ga.dfrag = plan->d_dfrag;
+        ga.melw = plan->d_melw; ga.mel_start = plan->d_mel_start; ga.mel_filt = plan->d_mel_filt;
+        ga.mel_pass = plan->d_mel_pass;
+        ga.mel_out = mel_out; ga.spec_out = spec_out; ga.gmax = gmax;
+        ga.n_pass = plan->sm.n_pass; ga.n_mels = plan->r.c.n_mels;
+        ga.n_fft = plan->r.c.n_fft; ga.n_bins = plan->r.n_bins;
+        ga.kpad = plan->g_kpad; ga.n_coltiles = plan->g_coltiles; ga.lda = plan->g_lda; ga.ldp = plan->g_ldp;
+        ga.hop = plan->r.c.hop_length;
+        ga.pad = plan->r.c.center ? plan->r.c.n_fft / 2 : 0;
+        ga.reflect = plan->r.c.pad_mode == MFCC_PAD_REFLECT;
+        ga.pw_mode = plan->r.c.power == 2.0f ? 0 : (plan->r.c.power == 1.0f ? 1 : 2);
+        ga.half_power = 0.5f * plan->r.c.power;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)k2048::LDS_LIMIT / plan->g_lds_bytes));
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(L.ub_tiles, (int64_t)plan->n_cu * per_cu));
+        if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
+        if (plan->r.c.power == 2.0f)
+            hipLaunchKernelGGL(k_melspec_generic<0>, dim3(grid), dim3(256), plan->g_lds_bytes, st, ga);
+        else
+            hipLaunchKernelGGL(k_melspec_generic<1>, dim3(grid), dim3(256), plan->g_lds_bytes, st, ga);
+        if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[1], st));
+        HIP_TRY(hipGetLastError());
+        return MFCC_OK;
+    }
     FrontArgs fa;
     fa.pcm = d_pcm; fa.tiles = tiles; fa.hdr = hdr;
     fa.window = plan->d_window; fa.tw1 = plan->d_tw1; fa.w64 = plan->d_w64; fa.tw128 = plan->d_tw128;

@@ -39,7 +39,10 @@ class MfccPlan:
         cfg_c, keep = config.to_c()
         self._cfg_c, self._keep = cfg_c, keep
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().mfcc_plan_create(C.byref(cfg_c), C.byref(self._handle)))
+            rc = _lib.lib().mfcc_plan_create(C.byref(cfg_c), C.byref(self._handle))
+        if rc == _lib.MFCC_E_INVALID:     # the cases librosa reports as ParameterError
+            raise ParameterError(_lib.last_error())
+        _lib.check(rc)
         self._ws: Optional[torch.Tensor] = None
 
     def close(self):
