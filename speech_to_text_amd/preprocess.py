@@ -1,0 +1,169 @@
+"""Host-side mirror of the reference's preprocessing driver.
+
+``Preprocessor`` keeps the method names, argument meaning and file schema of
+``SpeechToTextTrainer`` (/root/reference/src/preprocess.py:53-176) for the MFCC path:
+
+    process_audio(item)           :131-144   one utterance -> mfcc/{spk}_{chap}_{utt}.hdf5
+    preprocess(multiprocess)      :146-167   the loop over the dataset
+    read_preprocessed_data()      :169-176   walk mfcc/ and print datasets + attrs
+
+The arithmetic runs on the GPU in ragged batches; audio decode and resampling stay on the host
+(the dataset is any iterable of LibriSpeech-style items, e.g. torchaudio.datasets.LIBRISPEECH as
+the reference builds it at :75).  Where the reference parallelises over worker processes
+(``multiprocess=True``), this driver parallelises the file writing over threads instead.
+"""
+from __future__ import annotations
+
+import os
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import hdf5_min
+from .shard import lpt_shards, pack_batches
+
+Item = Tuple  # (waveform (1, T) float32 tensor-or-ndarray, sample_rate, transcript, speaker, chapter, utterance)
+
+
+def _waveform_to_numpy(samples) -> np.ndarray:
+    if hasattr(samples, "detach"):          # torch.Tensor, as torchaudio yields
+        samples = samples.detach().cpu().numpy()
+    return np.asarray(samples)
+
+
+def feature_file_name(speaker_id, chapter_id, utterance_id) -> str:
+    """/root/reference/src/preprocess.py:138."""
+    return f"{speaker_id}_{chapter_id}_{utterance_id}.hdf5"
+
+
+def write_feature_file(path, mfcc_frames: np.ndarray, *, speaker_id, chapter_id, utterance_id,
+                       sample_rate, transcript, backend: Optional[str] = None) -> str:
+    """Dataset ``mfccs`` + the five attributes of /root/reference/src/preprocess.py:139-144.
+    backend: 'h5py' (if importable), 'min' (the built-in writer) or None = h5py when available."""
+    attrs = dict(speaker_id=int(speaker_id), chapter_id=int(chapter_id), utterance_id=int(utterance_id),
+                 sample_rate=int(sample_rate), transcript=str(transcript))
+    if backend in (None, "h5py"):
+        try:
+            import h5py  # noqa: WPS433
+
+            with h5py.File(path, "w") as f:
+                ds = f.create_dataset("mfccs", data=mfcc_frames)
+                for k, v in attrs.items():
+                    ds.attrs[k] = v
+            return "h5py"
+        except ImportError:
+            if backend == "h5py":
+                raise
+    hdf5_min.write_features(path, mfcc_frames, attrs, name="mfccs")
+    return "min"
+
+
+def read_feature_file(path):
+    """(mfccs array, attrs dict) -- the reads of /root/reference/src/trainer.py:110-114."""
+    try:
+        import h5py  # noqa: WPS433
+
+        with h5py.File(path, "r") as f:
+            ds = f["mfccs"]
+            attrs = {k: (v.decode() if isinstance(v, bytes) else (int(v) if np.ndim(v) == 0 and not isinstance(v, str) else v))
+                     for k, v in ds.attrs.items()}
+            return ds[:], attrs
+    except ImportError:
+        return hdf5_min.read_features(path, "mfccs")
+
+
+class Preprocessor:
+    """Arguments
+    - data: iterable (ideally a sequence) of items
+      ``(waveform, sample_rate, transcript, speaker_id, chapter_id, utterance_id)``
+      (/root/reference/src/preprocess.py:132)
+    - out_dir: where the per-utterance files go ('mfcc', relative to the CWD, in the reference)
+    - rank / world_size: this process's shard of the utterances (one process per GPU)
+    """
+
+    def __init__(self, data: Optional[Iterable[Item]] = None, out_dir: str = "mfcc", *, device=None,
+                 rank: int = 0, world_size: int = 1, max_batch_seconds: float = 1800.0,
+                 hdf5_backend: Optional[str] = None, extractor=None):
+        # MFCC meta parameters, as /root/reference/src/preprocess.py:60-62
+        self.hop_length = 512
+        self.n_fft = 2048
+        self.n_mfcc = 13
+        self.data = data
+        self.out_dir = Path(out_dir)
+        self.device = device
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.max_batch_seconds = float(max_batch_seconds)
+        self.hdf5_backend = hdf5_backend
+        self._extract = extractor          # injectable for host-only tests
+
+    # ------------------------------------------------------------------------------------
+    def _features(self, waveforms: Sequence[np.ndarray]) -> List[np.ndarray]:
+        if self._extract is not None:
+            return self._extract(waveforms, n_fft=self.n_fft, hop_length=self.hop_length, n_mfcc=self.n_mfcc)
+        from .feature import mfcc_batch
+
+        return mfcc_batch(waveforms, n_fft=self.n_fft, hop_length=self.hop_length, n_mfcc=self.n_mfcc,
+                          device=self.device)
+
+    def _write(self, item: Item, frames: np.ndarray) -> None:
+        _, sample_rate, transcript, speaker_id, chapter_id, utterance_id = item
+        path = self.out_dir / feature_file_name(speaker_id, chapter_id, utterance_id)
+        write_feature_file(path, frames, speaker_id=speaker_id, chapter_id=chapter_id,
+                           utterance_id=utterance_id, sample_rate=sample_rate, transcript=transcript,
+                           backend=self.hdf5_backend)
+
+    def process_audio(self, item: Item) -> None:
+        """/root/reference/src/preprocess.py:131-144 for one item."""
+        self.out_dir.mkdir(parents=True, exist_ok=True)
+        samples = _waveform_to_numpy(item[0])
+        frames = self._features([samples])[0]          # == librosa.feature.mfcc(y=samples)[0].T
+        self._write(item, frames)
+
+    def preprocess(self, multiprocess: bool = False, verbose: bool = True) -> int:
+        """/root/reference/src/preprocess.py:146-167: every item of ``self.data`` -> one file.
+        Returns the number of files this rank wrote."""
+        if self.data is None:
+            print("Data is empty. Aborted.")
+            return 0
+        self.out_dir.mkdir(parents=True, exist_ok=True)
+        items = list(self.data)
+        lengths = np.asarray([_waveform_to_numpy(it[0]).shape[-1] for it in items], dtype=np.int64)
+        costs = 1 + lengths // self.hop_length
+        mine = lpt_shards(costs, self.world_size)[self.rank] if self.world_size > 1 else np.arange(len(items))
+        sr = int(items[0][1]) if items else 16000
+        batches = pack_batches(lengths[mine], int(self.max_batch_seconds * sr))
+        n_threads = max(1, min(16, (os.cpu_count() or 2) - 1)) if multiprocess else 1
+        if verbose:
+            print(f"Processing audio data... rank {self.rank}/{self.world_size}: {len(mine)} of {len(items)} "
+                  f"utterances in {len(batches)} GPU batch(es), {n_threads} writer thread(s)")
+        done = 0
+        with ThreadPoolExecutor(max_workers=n_threads) as pool:
+            pending = []
+            for b in batches:
+                idx = mine[b]
+                feats = self._features([_waveform_to_numpy(items[i][0]) for i in idx])
+                for f in pending:
+                    f.result()
+                pending = [pool.submit(self._write, items[i], fr) for i, fr in zip(idx, feats)]
+                done += len(idx)
+                if verbose:
+                    print(f"Progress: {done}/{len(mine)}", end="\r")
+            for f in pending:
+                f.result()
+        if verbose:
+            print()
+        return done
+
+    def read_preprocessed_data(self):
+        """/root/reference/src/preprocess.py:169-176."""
+        out = []
+        for root, _dirs, files in os.walk(self.out_dir):
+            for file in sorted(files):
+                arr, attrs = read_feature_file(Path(root) / file)
+                print(f'<HDF5 dataset "mfccs": shape {arr.shape}, type "<f4">')
+                for k, v in attrs.items():
+                    print(f"{k}: {v}")
+                out.append((file, arr, attrs))
+        return out

@@ -1,0 +1,143 @@
+"""No-GPU checks of the C ABI: the library loads, exports every symbol include/mfcc_hip.h
+declares, and its host-only table builders agree with the oracle."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.fftpack
+import scipy.signal
+
+from oracle import mfcc_ref as R
+from speech_to_text_amd import _lib
+from speech_to_text_amd.config import MfccConfig, ParameterError, make_config
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_functions():
+    text = (ROOT / "include" / "mfcc_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mfcc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    names = declared_functions()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/mfcc_hip.h but not exported"
+        assert n in _lib.SYMBOLS, f"{n} has no ctypes prototype in speech_to_text_amd/_lib.py"
+    assert lib.mfcc_abi_version() == _lib.ABI_VERSION
+
+
+def test_config_struct_matches_header_defaults():
+    lib = _lib.lib()
+    c = _lib.MfccConfigC()
+    lib.mfcc_config_default(C.byref(c))
+    assert c.struct_size == C.sizeof(_lib.MfccConfigC)
+    assert (c.n_fft, c.hop_length, c.win_length, c.center, c.pad_mode) == (2048, 512, 0, 1, 0)
+    assert (c.sr, c.n_mels, c.fmin, c.fmax, c.htk, c.mel_norm) == (22050.0, 128, 0.0, 0.0, 0, 1)
+    assert c.power == 2.0 and c.ref == 1.0 and c.top_db == 80.0 and abs(c.amin - 1e-10) < 1e-16
+    assert (c.n_mfcc, c.dct_type, c.dct_norm, c.lifter) == (20, 2, 1, 0.0)
+
+
+def _mel(cfg: MfccConfig):
+    c, keep = cfg.to_c()
+    out = np.zeros((cfg.n_mels, 1 + cfg.n_fft // 2), np.float32)
+    _lib.check(_lib.lib().mfcc_host_mel_basis(C.byref(c), out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+@pytest.mark.parametrize("kw", [
+    dict(), dict(sr=16000, n_fft=400, n_mels=80), dict(sr=16000, n_fft=512, n_mels=80),
+    dict(htk=True), dict(fmin=50.0, fmax=7600.0, sr=16000, n_mels=40), dict(mel_norm=None, n_mels=64),
+    dict(sr=44100, n_fft=1024, n_mels=96),
+])
+def test_host_mel_basis_is_librosas(kw):
+    cfg = MfccConfig(**kw)
+    want = R.mel(sr=cfg.sr, n_fft=cfg.n_fft, n_mels=cfg.n_mels, fmin=cfg.fmin, fmax=cfg.fmax,
+                 htk=cfg.htk, norm=cfg.mel_norm)
+    got = _mel(cfg)
+    # same float64 formulas, same two roundings to float32: bit-identical up to libm's last ulp
+    np.testing.assert_allclose(got, want, rtol=2e-7, atol=0)
+    assert ((got != 0) == (want != 0)).all()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_fft=512, win_length=400), dict(n_fft=400), dict(window="hamming"),
+                                dict(n_fft=1024, win_length=1000, window=("kaiser", 8.0))])
+def test_host_window(kw):
+    cfg = make_config(**kw)
+    c, keep = cfg.to_c()
+    out = np.zeros(cfg.n_fft)
+    _lib.check(_lib.lib().mfcc_host_window(C.byref(c), out.ctypes.data_as(C.POINTER(C.c_double))))
+    wl = cfg.win_length or cfg.n_fft
+    want = R.pad_center(R.get_window(kw.get("window", "hann"), wl), size=cfg.n_fft)
+    np.testing.assert_allclose(out, want, rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("dct_type", [1, 2, 3])
+@pytest.mark.parametrize("norm", ["ortho", None])
+def test_host_dct_basis_is_scipys(dct_type, norm):
+    cfg = MfccConfig(n_mels=80, n_mfcc=20, dct_type=dct_type, norm=norm)
+    c, _ = cfg.to_c()
+    out = np.zeros((20, 80), np.float32)
+    _lib.check(_lib.lib().mfcc_host_dct_basis(C.byref(c), out.ctypes.data_as(C.POINTER(C.c_float))))
+    want = scipy.fftpack.dct(np.eye(80), axis=0, type=dct_type, norm=norm)[:20]
+    np.testing.assert_allclose(out, want, atol=2e-7 * max(1.0, np.abs(want).max()))
+
+
+def test_num_frames_and_batch_layout():
+    lib = _lib.lib()
+    c, _ = MfccConfig.reference_default().to_c()
+    for T in (0, 1, 511, 512, 513, 2048, 166960):
+        assert lib.mfcc_num_frames(C.byref(c), T) == 1 + T // 512
+    c2, _ = MfccConfig(center=False).to_c()
+    assert lib.mfcc_num_frames(C.byref(c2), 2047) < 0
+    assert lib.mfcc_num_frames(C.byref(c2), 2048) == 1 and lib.mfcc_num_frames(C.byref(c2), 2048 + 512) == 2
+    lens = np.array([166960, 0, 5, 32000, 560000])
+    so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    fo = np.zeros_like(so)
+    _lib.check(lib.mfcc_batch_layout(C.byref(c), so.ctypes.data_as(C.POINTER(C.c_int64)), len(lens),
+                                     fo.ctypes.data_as(C.POINTER(C.c_int64))))
+    assert np.array_equal(np.diff(fo), 1 + lens // 512)
+    rc = lib.mfcc_batch_layout(C.byref(c2), so.ctypes.data_as(C.POINTER(C.c_int64)), len(lens),
+                               fo.ctypes.data_as(C.POINTER(C.c_int64)))
+    assert rc == _lib.MFCC_E_INVALID and "uncentered" in _lib.last_error()
+
+
+@pytest.mark.parametrize("field,value", [("n_fft", 0), ("n_fft", 401), ("hop_length", 0), ("win_length", 4096),
+                                         ("n_mfcc", 0), ("n_mfcc", 129), ("dct_type", 4), ("amin", 0.0),
+                                         ("lifter", -1.0), ("pad_mode", 7), ("struct_size", 8)])
+def test_invalid_configs_are_rejected_on_the_host(field, value):
+    lib = _lib.lib()
+    c = _lib.MfccConfigC()
+    lib.mfcc_config_default(C.byref(c))
+    setattr(c, field, value)
+    out = np.zeros(10_000_000 // 8, np.float64)  # large enough for any table that would be written
+    rc = lib.mfcc_host_window(C.byref(c), out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == _lib.MFCC_E_INVALID and _lib.last_error()
+
+
+def test_python_config_validation():
+    for kw in [dict(hop_length=0), dict(pad_mode="wrap"), dict(amin=0), dict(top_db=-1), dict(lifter=-2),
+               dict(norm="l2"), dict(mel_norm="l1")]:
+        with pytest.raises(ParameterError):
+            MfccConfig(**kw).to_c()
+    with pytest.raises(ParameterError):
+        make_config(window=np.ones(100)).to_c()          # window size mismatch
+    assert make_config(window=np.ones(2048)) == make_config(window=np.ones(2048))
+    assert hash(make_config(window=np.ones(2048))) == hash(make_config(window=np.ones(2048)))
+    assert MfccConfig.reference_default() == MfccConfig(n_fft=2048, hop_length=512, n_mfcc=13)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    import speech_to_text_amd as S
+
+    with pytest.raises(RuntimeError):
+        S.mfcc(y=np.zeros(4096, np.float32))

@@ -1,0 +1,122 @@
+"""GPU tests of everything around the kernels: the raw C ABI (ctypes + device pointers), the
+preprocessing driver writing the reference's HDF5 schema, and the CMVN extension kernels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import mfcc_ref as R
+from tests.signals import ragged_lengths, speech_like
+
+pytestmark = pytest.mark.gpu
+
+
+def test_raw_c_abi(gpu):
+    """Calls include/mfcc_hip.h directly: config -> plan -> layout -> workspace -> execute."""
+    import torch
+
+    from speech_to_text_amd import _lib
+
+    lib = _lib.lib()
+    c = _lib.MfccConfigC()
+    lib.mfcc_config_default(C.byref(c))
+    c.n_mfcc = 13
+    plan = C.c_void_p()
+    _lib.check(lib.mfcc_plan_create(C.byref(c), C.byref(plan)))
+    try:
+        ys = [speech_like(n, seed=i) for i, n in enumerate([30000, 2048, 51234])]
+        so = np.concatenate([[0], np.cumsum([len(y) for y in ys])]).astype(np.int64)
+        fo = np.zeros_like(so)
+        _lib.check(lib.mfcc_batch_layout(C.byref(c), so.ctypes.data_as(C.POINTER(C.c_int64)), 3,
+                                         fo.ctypes.data_as(C.POINTER(C.c_int64))))
+        F = int(fo[-1])
+        pcm = torch.from_numpy(np.concatenate(ys)).to(gpu)
+        d_so, d_fo = torch.from_numpy(so).to(gpu), torch.from_numpy(fo).to(gpu)
+        out = torch.full((F, 13), float("nan"), device=gpu)
+        mel = torch.empty((F, 128), device=gpu)
+        need = lib.mfcc_workspace_bytes(plan, F, 3)
+        ws = torch.empty(need, dtype=torch.uint8, device=gpu)
+        # too small a workspace is an error, not a fault
+        rc = lib.mfcc_execute(plan, pcm.data_ptr(), d_so.data_ptr(), d_fo.data_ptr(), None, 3, F,
+                              out.data_ptr(), None, ws.data_ptr(), 16, None)
+        assert rc == _lib.MFCC_E_WORKSPACE and "workspace" in _lib.last_error()
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.mfcc_execute(plan, pcm.data_ptr(), d_so.data_ptr(), d_fo.data_ptr(), None, 3, F,
+                                    out.data_ptr(), mel.data_ptr(), ws.data_ptr(), need, stream))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for i, y in enumerate(ys):
+            np.testing.assert_allclose(got[fo[i]:fo[i + 1]], R.process_audio_features(y), rtol=0, atol=1e-2)
+        melh = mel.cpu().numpy()
+        want = R.melspectrogram(y=ys[0], n_fft=2048, hop_length=512).T
+        assert (np.abs(melh[:fo[1]] - want) <= 1e-4 * want + 2e-7 * want.max()).all()
+        # an empty batch is a no-op
+        assert lib.mfcc_execute(plan, None, None, None, None, 0, 0, None, None, None, 0, None) == 0
+    finally:
+        lib.mfcc_plan_destroy(plan)
+
+
+def test_driver_writes_reference_files(gpu, tmp_path):
+    """Preprocessor.preprocess on the GPU: same files, names, dataset and attributes as
+    /root/reference/src/preprocess.py:131-167 would write."""
+    import speech_to_text_amd as S
+
+    lens = ragged_lengths(12, 0.5, 4.0, seed=8)
+    items = [(speech_like(int(L), seed=40 + i, int16_grid=True)[None, :], 16000, f"UTTERANCE {i}", 100 + i, 200 + i, i)
+             for i, L in enumerate(lens)]
+    pre = S.Preprocessor(items, out_dir=tmp_path / "mfcc", hdf5_backend="min", max_batch_seconds=10.0)
+    assert pre.preprocess(multiprocess=True, verbose=False) == 12
+    for i, it in enumerate(items):
+        arr, attrs = S.read_feature_file(tmp_path / "mfcc" / f"{100 + i}_{200 + i}_{i}.hdf5")
+        want = R.process_audio_features(it[0])
+        assert arr.dtype == np.float32 and arr.shape == want.shape
+        np.testing.assert_allclose(arr, want, rtol=0, atol=1e-2)
+        assert attrs == dict(speaker_id=100 + i, chapter_id=200 + i, utterance_id=i, sample_rate=16000,
+                             transcript=f"UTTERANCE {i}")
+    pre.process_audio(items[0])      # the single-item entry point overwrites in place ('w' mode)
+
+
+def test_cmvn_kernels(gpu):
+    import torch
+
+    import speech_to_text_amd as S
+
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((50_001, 13)) * np.linspace(1, 30, 13) + np.linspace(-400, 40, 13)).astype(np.float32)
+    d = torch.from_numpy(x).to(gpu)
+    stats = S.cmvn.new_stats(13, gpu)
+    S.cmvn.accumulate(d[:20_000].contiguous(), stats)
+    S.cmvn.accumulate(d[20_000:].contiguous(), stats)
+    S.cmvn.allreduce(stats)                                  # single process: no-op
+    s = stats.cpu().numpy()
+    x64 = x.astype(np.float64)
+    np.testing.assert_allclose(s[:13], x64.sum(0), rtol=1e-12)
+    np.testing.assert_allclose(s[13:26], (x64 ** 2).sum(0), rtol=1e-12)
+    assert s[26] == x.shape[0]
+    mean, std = S.cmvn.mean_std(stats)
+    S.cmvn.apply(d, stats)
+    got = d.cpu().numpy()
+    np.testing.assert_allclose(got, (x64 - mean) / std, rtol=0, atol=2e-5)
+    assert abs(got.mean(0)).max() < 1e-4 and abs(got.std(0) - 1).max() < 1e-4
+
+
+def test_asr_frontend_with_cmvn(gpu):
+    """BASELINE config 4 end to end on one GPU: n_fft=400 (and the n_fft=512 / win_length=400
+    spelling), hop=160, 80 mels, 13 MFCC, global CMVN."""
+    import torch
+
+    import speech_to_text_amd as S
+
+    ys = [speech_like(int(n), seed=70 + i) for i, n in enumerate(ragged_lengths(6, 0.5, 3.0, seed=2))]
+    for kw in (dict(n_fft=400), dict(n_fft=512, win_length=400)):
+        feats = S.mfcc_batch(ys, sr=16000, hop_length=160, n_mels=80, n_mfcc=13, return_tensor=True, **kw)
+        want = [R.mfcc(y=y, sr=16000, hop_length=160, n_mels=80, n_mfcc=13, **kw).T for y in ys]
+        for f, w in zip(feats, want):
+            assert f.shape == w.shape == (1 + len(ys[0]) // 160, 13) or f.shape == w.shape
+            np.testing.assert_allclose(f.cpu().numpy(), w, rtol=0, atol=1e-2)
+        allf = torch.cat(feats).contiguous()
+        stats = S.cmvn.new_stats(13, allf.device)
+        S.cmvn.accumulate(allf, stats)
+        S.cmvn.apply(allf, stats)
+        w = np.concatenate(want).astype(np.float64)
+        np.testing.assert_allclose(allf.cpu().numpy(), (w - w.mean(0)) / w.std(0), rtol=0, atol=2e-3)

@@ -1,0 +1,127 @@
+"""Host-side logic without a GPU: sharding, HDF5 schema round trips, the preprocessing driver
+(with the oracle injected as the feature extractor)."""
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import mfcc_ref as R
+from speech_to_text_amd import hdf5_min
+from speech_to_text_amd.preprocess import Preprocessor, feature_file_name, read_feature_file, write_feature_file
+from speech_to_text_amd.shard import lpt_shards, pack_batches, shard_loads
+from tests.signals import ragged_lengths, speech_like
+
+
+def oracle_extractor(waveforms, *, n_fft, hop_length, n_mfcc):
+    return [R.process_audio_features(np.asarray(w), n_fft=n_fft, hop_length=hop_length, n_mfcc=n_mfcc) for w in waveforms]
+
+
+def make_items(n, seed=0):
+    lens = ragged_lengths(n, 0.2, 1.5, seed)
+    return [(speech_like(int(L), seed=seed * 100 + i)[None, :], 16000, f"TRANSCRIPT NUMBER {i} ü", 1000 + i, 2000 + i, i)
+            for i, L in enumerate(lens)]
+
+
+# ---- sharding -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_ranks", [1, 2, 4, 8])
+def test_lpt_shards_partition_and_balance(n_ranks):
+    costs = 1 + ragged_lengths(1946, 2, 35, seed=1234) // 512
+    shards = lpt_shards(costs, n_ranks)
+    allidx = np.sort(np.concatenate(shards))
+    assert np.array_equal(allidx, np.arange(len(costs)))          # a partition: nothing lost or doubled
+    loads = shard_loads(costs, shards)
+    assert loads.max() - loads.min() <= costs.max()               # LPT bound
+    assert loads.max() <= 1.01 * costs.sum() / n_ranks + costs.max()
+    again = lpt_shards(costs, n_ranks)
+    assert all(np.array_equal(a, b) for a, b in zip(shards, again))   # deterministic
+
+
+def test_lpt_edge_cases():
+    assert [len(s) for s in lpt_shards([], 4)] == [0, 0, 0, 0]
+    s = lpt_shards([5], 3)
+    assert sorted(len(x) for x in s) == [0, 0, 1]
+    with pytest.raises(ValueError):
+        lpt_shards([1, 2], 0)
+
+
+def test_pack_batches():
+    b = pack_batches([10, 20, 30, 100, 5, 5], 50)
+    assert [x.tolist() for x in b] == [[0, 1], [2], [3], [4, 5]]
+    assert pack_batches([], 10) == []
+
+
+# ---- HDF5 schema ----------------------------------------------------------------------------------
+def test_hdf5_roundtrip_schema(tmp_path):
+    a = np.random.default_rng(0).standard_normal((327, 13)).astype(np.float32)
+    p = tmp_path / feature_file_name(1272, 128104, 3)
+    assert p.name == "1272_128104_3.hdf5"
+    write_feature_file(p, a, speaker_id=1272, chapter_id=128104, utterance_id=3, sample_rate=16000,
+                       transcript="MISTER QUILTER IS THE APOSTLE OF THE MIDDLE CLASSES", backend="min")
+    arr, attrs = hdf5_min.read_features(p)
+    assert arr.dtype == np.float32 and arr.shape == (327, 13) and np.array_equal(arr, a)
+    assert attrs == dict(speaker_id=1272, chapter_id=128104, utterance_id=3, sample_rate=16000,
+                         transcript="MISTER QUILTER IS THE APOSTLE OF THE MIDDLE CLASSES")
+    arr2, attrs2 = read_feature_file(p)
+    assert np.array_equal(arr2, a) and attrs2["transcript"] == attrs["transcript"]
+
+
+def test_hdf5_non_contiguous_input_and_empty(tmp_path):
+    m = np.random.default_rng(1).standard_normal((13, 50)).astype(np.float32)
+    write_feature_file(tmp_path / "t.hdf5", m.T, speaker_id=1, chapter_id=2, utterance_id=3, sample_rate=16000,
+                       transcript="", backend="min")          # mfccs[0].T is a non-contiguous view (preprocess.py:136)
+    arr, attrs = hdf5_min.read_features(tmp_path / "t.hdf5")
+    assert np.array_equal(arr, m.T) and attrs["transcript"] == ""
+    hdf5_min.write_features(tmp_path / "e.hdf5", np.zeros((0, 13), np.float32), {"speaker_id": -5})
+    arr, attrs = hdf5_min.read_features(tmp_path / "e.hdf5")
+    assert arr.shape == (0, 13) and attrs == {"speaker_id": -5}
+    with pytest.raises(TypeError):
+        hdf5_min.write_features(tmp_path / "x.hdf5", np.zeros((1, 1), np.float32), {"bad": 1.5})
+
+
+def test_hdf5_is_readable_by_libhdf5(tmp_path):
+    """When the HDF5 command-line tools exist, libhdf5 itself must read the file back."""
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if shutil.os.path.exists("/opt/conda/bin/h5dump") else None)
+    if h5dump is None:
+        pytest.skip("no h5dump on this machine")
+    a = (np.arange(26, dtype=np.float32) / 4).reshape(2, 13)
+    p = tmp_path / "1_2_3.hdf5"
+    write_feature_file(p, a, speaker_id=1, chapter_id=2, utterance_id=3, sample_rate=16000, transcript="HELLO WORLD", backend="min")
+    out = subprocess.run([h5dump, str(p)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    txt = out.stdout
+    assert 'DATASET "mfccs"' in txt and "H5T_IEEE_F32LE" in txt and "( 2, 13 ) / ( 2, 13 )" in txt
+    for name in ("speaker_id", "chapter_id", "utterance_id", "sample_rate", "transcript"):
+        assert f'ATTRIBUTE "{name}"' in txt
+    assert "H5T_STD_I64LE" in txt and "H5T_VARIABLE" in txt and "H5T_CSET_UTF8" in txt and '"HELLO WORLD"' in txt
+    assert "6.25" in txt          # last element
+
+
+# ---- the driver -------------------------------------------------------------------------------------------
+def test_preprocessor_writes_reference_schema(tmp_path, capsys):
+    items = make_items(7)
+    pre = Preprocessor(items, out_dir=tmp_path / "mfcc", extractor=oracle_extractor, hdf5_backend="min")
+    assert (pre.hop_length, pre.n_fft, pre.n_mfcc) == (512, 2048, 13)      # preprocess.py:60-62
+    assert pre.preprocess(multiprocess=True, verbose=False) == 7
+    files = sorted(p.name for p in (tmp_path / "mfcc").iterdir())
+    assert files == sorted(f"{1000 + i}_{2000 + i}_{i}.hdf5" for i in range(7))
+    for i, it in enumerate(items):
+        arr, attrs = read_feature_file(tmp_path / "mfcc" / f"{1000 + i}_{2000 + i}_{i}.hdf5")
+        want = R.process_audio_features(it[0])
+        assert arr.shape == (1 + it[0].shape[-1] // 512, 13) and np.array_equal(arr, want)
+        assert attrs == dict(speaker_id=1000 + i, chapter_id=2000 + i, utterance_id=i, sample_rate=16000,
+                             transcript=f"TRANSCRIPT NUMBER {i} ü")
+    listed = pre.read_preprocessed_data()
+    assert len(listed) == 7 and "transcript: TRANSCRIPT NUMBER" in capsys.readouterr().out
+
+
+def test_preprocessor_process_audio_and_sharding(tmp_path):
+    items = make_items(9, seed=3)
+    Preprocessor(out_dir=tmp_path / "one", extractor=oracle_extractor, hdf5_backend="min").process_audio(items[0])
+    assert (tmp_path / "one" / "1000_2000_0.hdf5").exists()
+    n = 0
+    for r in range(2):
+        n += Preprocessor(items, out_dir=tmp_path / "two", rank=r, world_size=2, extractor=oracle_extractor,
+                          hdf5_backend="min", max_batch_seconds=1.0).preprocess(verbose=False)
+    assert n == 9 and len(list((tmp_path / "two").iterdir())) == 9
+    assert Preprocessor(None, out_dir=tmp_path / "none").preprocess(verbose=False) == 0

@@ -1,0 +1,162 @@
+"""Pins for the CPU oracle (oracle/mfcc_ref.py).
+
+The reference ships no tests or fixtures and librosa cannot be installed here, so the oracle is
+pinned by (a) the known-answer values librosa's own documentation prints for its mel helpers and
+filterbank, (b) independent implementations of each stage, (c) analytic signals.
+"""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.fftpack
+
+from oracle import mfcc_ref as R
+from tests.signals import speech_like
+
+
+# ---- (a) librosa's documented known answers -----------------------------------------------------
+def test_hz_mel_doc_values():
+    assert R.hz_to_mel(60) == pytest.approx(0.9)
+    np.testing.assert_allclose(R.hz_to_mel(np.array([110.0, 220.0, 440.0])), [1.65, 3.3, 6.6])
+    assert R.mel_to_hz(3) == pytest.approx(200.0)
+    np.testing.assert_allclose(R.mel_to_hz(np.array([1.0, 2, 3, 4, 5])), [66.667, 133.333, 200.0, 266.667, 333.333], atol=1e-3)
+
+
+def test_mel_frequencies_doc_values():
+    mf = R.mel_frequencies(n_mels=40)
+    doc = {0: 0.0, 1: 85.317, 2: 170.635, 12: 1024.856, 38: 10096.408, 39: 11025.0}
+    for i, v in doc.items():
+        assert mf[i] == pytest.approx(v, abs=2e-3)
+
+
+def test_filters_mel_doc_values():
+    M = R.mel(sr=22050, n_fft=2048)
+    assert M.shape == (128, 1025) and M.dtype == np.float32
+    assert M[0, 0] == 0.0 and M[0, 1] == pytest.approx(0.016, abs=5e-4) and M[0, 2] == pytest.approx(0.032, abs=5e-4)
+    assert (M[-1, :3] == 0).all()
+    assert (M != 0).sum() == 2018 and (M != 0).sum(axis=0).max() == 2
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # no empty-filter warning for the ASR front ends
+        assert (R.mel(sr=16000, n_fft=400, n_mels=80).max(axis=1) > 0).all()
+        assert (R.mel(sr=16000, n_fft=512, n_mels=80).max(axis=1) > 0).all()
+    Mh = R.mel(sr=22050, n_fft=2048, fmax=8000)
+    assert Mh[-1, -1] == 0.0
+
+
+# ---- (b) independent implementations ----------------------------------------------------------------
+def test_stft_matches_explicit_dft():
+    y = speech_like(3000, seed=1)
+    n_fft, hop = 256, 64
+    S = R.stft(y, n_fft=n_fft, hop_length=hop)
+    assert S.dtype == np.complex64 and S.shape == (129, 1 + 3000 // hop)
+    yp = np.pad(y.astype(np.float64), n_fft // 2)
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)
+    n = np.arange(n_fft)
+    D = np.exp(-2j * np.pi * np.outer(np.arange(129), n) / n_fft)
+    for t in (0, 1, 7, S.shape[1] - 1):
+        want = D @ (w * yp[t * hop:t * hop + n_fft])
+        np.testing.assert_allclose(S[:, t], want, rtol=0, atol=2e-5 * np.abs(want).max())
+
+
+def test_dct_matches_cosine_matrix():
+    x = np.random.default_rng(0).uniform(-80, 20, size=(128, 7)).astype(np.float32)
+    N = 128
+    k = np.arange(N)[:, None]
+    n = np.arange(N)[None, :]
+    C = np.sqrt(2.0 / N) * np.cos(np.pi * k * (2 * n + 1) / (2 * N))
+    C[0] *= np.sqrt(0.5)
+    got = scipy.fftpack.dct(x, axis=0, type=2, norm="ortho")
+    np.testing.assert_allclose(got, C @ x.astype(np.float64), atol=2e-4)
+
+
+def test_mfcc_is_composition_of_stages():
+    y = speech_like(20000, seed=3)
+    S = np.abs(R.stft(y, n_fft=2048, hop_length=512)) ** 2
+    mel = R.mel(sr=22050, n_fft=2048) @ S
+    db = 10 * np.log10(np.maximum(1e-10, mel))
+    db = np.maximum(db, db.max() - 80)
+    want = scipy.fftpack.dct(db, axis=0, type=2, norm="ortho")[:13]
+    got = R.mfcc(y=y, n_fft=2048, hop_length=512, n_mfcc=13)
+    np.testing.assert_allclose(got, want, atol=2e-3)
+    assert got.dtype == np.float32
+
+
+# ---- (c) analytic signals ------------------------------------------------------------------------------
+def test_silence():
+    f = R.process_audio_features(np.zeros(4096, np.float32))
+    assert f.shape == (9, 13)
+    np.testing.assert_allclose(f[:, 0], -100 * np.sqrt(128.0), rtol=1e-6)
+    np.testing.assert_allclose(f[:, 1:], 0, atol=1e-3)
+
+
+def test_bin_centred_sinusoid():
+    n_fft, k0, A = 2048, 100, 0.5
+    y = (A * np.cos(2 * np.pi * k0 * np.arange(8 * n_fft) / n_fft)).astype(np.float32)
+    S = np.abs(R.stft(y, n_fft=n_fft, hop_length=512))
+    t = S.shape[1] // 2                                   # an interior frame
+    assert S[k0, t] == pytest.approx(A * n_fft / 4, rel=1e-4)
+    assert S[k0 - 1, t] == pytest.approx(A * n_fft / 8, rel=1e-3)
+    assert S[k0 + 1, t] == pytest.approx(A * n_fft / 8, rel=1e-3)
+    assert np.delete(S[:, t], [k0 - 1, k0, k0 + 1]).max() < 1e-2
+
+
+def test_impulse_is_flat():
+    n_fft, hop = 2048, 512
+    y = np.zeros(6000, np.float32)
+    y[3000] = 1.0
+    S = np.abs(R.stft(y, n_fft=n_fft, hop_length=hop)) ** 2
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)
+    for t in range(S.shape[1]):
+        pos = 3000 + n_fft // 2 - t * hop
+        want = w[pos] ** 2 if 0 <= pos < n_fft else 0.0
+        np.testing.assert_allclose(S[:, t], want, atol=1e-6)
+
+
+@pytest.mark.parametrize("T", [1, 511, 512, 513, 2047, 2048, 2049, 4096])
+def test_frame_count(T):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f = R.process_audio_features(speech_like(T, seed=T))
+    assert f.shape == (1 + T // 512, 13) and f.flags["C_CONTIGUOUS"]
+
+
+def test_pad_modes_differ_only_at_edges():
+    y = speech_like(20000, seed=4)
+    a = np.abs(R.stft(y, n_fft=2048, hop_length=512, pad_mode="constant"))
+    b = np.abs(R.stft(y, n_fft=2048, hop_length=512, pad_mode="reflect"))
+    F = a.shape[1]
+    inner = [t for t in range(F) if t * 512 >= 1024 and t * 512 + 1024 <= 20000]
+    assert np.array_equal(a[:, inner], b[:, inner])
+    assert not np.array_equal(a[:, 0], b[:, 0])
+
+
+def test_top_db_clamp_is_global_over_array():
+    y = np.stack([speech_like(8000, seed=1), 1e-4 * speech_like(8000, seed=2)])
+    db = R.power_to_db(R.melspectrogram(y=y, n_fft=2048, hop_length=512))
+    assert db.min() >= db.max() - 80.0 and db[1].min() == pytest.approx(db.max() - 80.0)
+
+
+def test_errors():
+    y = speech_like(4000, seed=0)
+    bad = y.copy(); bad[5] = np.nan
+    with pytest.raises(R.ParameterError):
+        R.mfcc(y=bad)
+    with pytest.raises(R.ParameterError):
+        R.mfcc(y=(y * 1000).astype(np.int16))
+    with pytest.raises(R.ParameterError):
+        R.mfcc(y=y, lifter=-1)
+    with pytest.raises(R.ParameterError):
+        R.power_to_db(np.ones(3), amin=0)
+    with pytest.raises(R.ParameterError):
+        R.power_to_db(np.ones(3), top_db=-1)
+    with pytest.raises(R.ParameterError):
+        R.stft(y[:100], n_fft=2048, center=False)
+    with pytest.warns(UserWarning):
+        R.stft(y[:100], n_fft=2048)
+
+
+def test_amplitude_to_db_identity():
+    S = np.abs(R.stft(speech_like(9000, seed=6), n_fft=2048, hop_length=512))
+    a = R.amplitude_to_db(S.copy())
+    b = R.power_to_db(S ** 2, ref=1.0, amin=1e-10, top_db=80.0)
+    np.testing.assert_allclose(a, b, atol=1e-4)
