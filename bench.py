@@ -188,6 +188,22 @@ def main():
         achieved = alg_front / (front * 1e-3) / 1e9
         # FFT-dominated flop model per frame (2.5 N log2 N + 3 B + 2 nnz(mel))
         flops_frame = 2.5 * 2048 * 11 + 3 * 1025 + 2 * 2018
+        # HBM bytes of the dominant kernel from the committed PMC passes (profiles/, made by
+        # tools/pmc_traffic.sh on this same command); only quoted when the workload is the same.
+        traffic, traffic_src = None, None
+        for cand in sorted((ROOT / "profiles").glob("*_pmc_traffic.json"), reverse=True):
+            try:
+                prof = json.loads(cand.read_text())
+                bl = prof.get("bench_line_under_profiler") or {}
+                if bl.get("config", {}).get("frames_per_gpu") != total_frames:
+                    continue
+                for kname, kv in prof["kernels"].items():
+                    if "k_melspec" in kname:
+                        traffic, traffic_src = kv["hbm_bytes"], f"profiles/{cand.name}: {kname}"
+                if traffic is not None:
+                    break
+            except Exception:
+                continue
         line = {
             "metric": "audio-hours of MFCC/sec",
             "value": value,
@@ -211,12 +227,13 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_melspec_2048 (pad+frame+window+rFFT+power+mel)",
+                "kernel": "k_melspec_2048 (pad+frame+window+rFFT+power+mel; PCM in -> mel power out)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel_ms": front,
                 "algorithmic_bytes_per_launch": alg_front,
                 "end_to_end_GBps": alg_e2e / ((front + dctm) * 1e-3) / 1e9,

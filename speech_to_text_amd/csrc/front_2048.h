@@ -155,9 +155,10 @@ __device__ __noinline__ void stage_edge_frame(float* X, const float* p, int star
 // WIN/TW1   where the window / step-1 twiddle tables live (k2048::TableHome)
 // W64_REGS  step-2 twiddles in registers instead of LDS
 // MELW_LDS  mel weights in LDS instead of streamed from global memory
-// PREFETCH  request the next frame's samples before transforming the current one
+// HOPR      0, or hop_length / 64 when that is an integer: samples shared with the previous frame
+//           stay in registers and only the new rows are loaded, one frame ahead
 // PW        0: |X|^2; 1: run-time power
-template <int WAVES, int WIN, int TW1, bool W64_REGS, bool MELW_LDS, bool PREFETCH, int PW>
+template <int WAVES, int WIN, int TW1, bool W64_REGS, bool MELW_LDS, int HOPR, int PW>
 __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) {
     using namespace k2048;
     constexpr int THREADS = WAVES * 64;
@@ -228,20 +229,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     int cur_grp = -1;
     const int n_tiles = a.hdr->n_tiles;
 
-    // Work unit = one frame slot (tile, frame-in-tile).  Each workgroup owns one contiguous
-    // block of slots and its wavefronts interleave inside it: neighbouring frames (75 % shared
-    // samples) are in flight together and hit L1/L2, and a wavefront stays within one
-    // utterance for many frames (one atomicMax per utterance change, not per frame).
+    // Work unit = one frame slot (tile, frame-in-tile).  Every wavefront of the grid owns one
+    // contiguous run of slots and walks it in order: consecutive frames of a run share 75 % of
+    // their samples, which the wavefront re-reads from L2 a few microseconds later (runs of
+    // different wavefronts do not overlap, so each sample leaves HBM once), and a wavefront
+    // stays within one utterance for many frames (one atomicMax per utterance change).
     const int64_t n_slots = (int64_t)n_tiles * TILE_FRAMES;
-    const int64_t slot_stride = WAVES;
-    const int64_t per_wg = ((n_slots + gridDim.x - 1) / gridDim.x + WAVES - 1) / WAVES * WAVES;
-    const int64_t slot_end = min(n_slots, (int64_t)(blockIdx.x + 1) * per_wg);
+    const int64_t slot_stride = 1;
+    const int64_t n_runs = (int64_t)gridDim.x * WAVES;
+    const int64_t per_run = (n_slots + n_runs - 1) / n_runs;
+    const int64_t run = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t slot_end = min(n_slots, (run + 1) * per_run);
 
     Tile ti;           // current work
     int t = 0;
-    bool have = false, interior = false;
-    int64_t slot = (int64_t)blockIdx.x * per_wg + wave;
-    float r[32];
+    int64_t slot = run * per_run;
 
     // find the first valid slot at or after `s`; wave-uniform
     auto next_valid = [&](int64_t s, Tile& o_ti, int& o_t, int64_t& o_slot) -> bool {
@@ -257,15 +259,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         return start >= 0 && start + NFFT <= c.T;
     };
 
-    have = next_valid(slot, ti, t, slot);
-    if (PREFETCH && have) {
-        interior = is_interior(ti, t);
-        if (interior) {
-            const float* pp = a.pcm + ti.soff + (t * a.hop - a.pad) + lane;
-#pragma unroll
-            for (int n2 = 0; n2 < 32; ++n2) r[n2] = pp[64 * n2];
-        }
-    }
+    bool have = next_valid(slot, ti, t, slot);
+    // HOPR > 0 (hop = 64 * HOPR): consecutive frames of a run share their rows n2 >= HOPR, so the
+    // unwindowed samples stay in registers, shift by HOPR rows per frame, and only the HOPR new
+    // rows are loaded -- requested one frame ahead.
+    float raw[HOPR > 0 ? 32 : 1];
+    float rn[HOPR > 0 ? HOPR : 1];
+    bool raw_ok = false, rn_ok = false;
 
     while (have) {
         if (ti.grp != cur_grp) {
@@ -274,38 +274,47 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             runmax = 0.0f;
         }
         const int64_t row = ti.row0 + (t - ti.f0);
-
-        // ---- samples: this frame's (no prefetch) or the next frame's (prefetch) ---------------
+        const bool interior = is_interior(ti, t);
         Tile ti_n;
         int t_n = 0;
         int64_t slot_n = 0;
-        bool interior_n = false;
-        float rn[PREFETCH ? 32 : 1];
         const bool have_n = next_valid(slot + slot_stride, ti_n, t_n, slot_n);
-        if (PREFETCH) {
-            if (have_n) {
-                interior_n = is_interior(ti_n, t_n);
-                if (interior_n) {
-                    const float* pp = a.pcm + ti_n.soff + (t_n * a.hop - a.pad) + lane;
+
+        // ---- samples --------------------------------------------------------------------------------
+        float r[32];
+        if (interior) {
+            const float* pp = a.pcm + ti.soff + (t * a.hop - a.pad) + lane;
+            if (HOPR > 0) {
+                if (raw_ok && rn_ok) {
 #pragma unroll
-                    for (int n2 = 0; n2 < 32; ++n2) rn[n2] = pp[64 * n2];
+                    for (int n2 = 0; n2 < 32 - HOPR; ++n2) raw[n2] = raw[n2 + HOPR];
+#pragma unroll
+                    for (int j = 0; j < HOPR; ++j) raw[32 - HOPR + j] = rn[j];
+                } else {
+#pragma unroll
+                    for (int n2 = 0; n2 < 32; ++n2) raw[n2] = pp[64 * n2];
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this frame's work
-        } else {
-            interior = is_interior(ti, t);
-            if (interior) {
-                const float* pp = a.pcm + ti.soff + (t * a.hop - a.pad) + lane;
+                raw_ok = true;
+                rn_ok = have_n && ti_n.soff == ti.soff && t_n == t + 1 && is_interior(ti_n, t_n);
+                if (rn_ok) {
+                    const float* pn = pp + a.hop + 64 * (32 - HOPR);
+#pragma unroll
+                    for (int j = 0; j < HOPR; ++j) rn[j] = pn[64 * j];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this frame's work
+#pragma unroll
+                for (int n2 = 0; n2 < 32; ++n2) r[n2] = raw[n2];
+            } else {
 #pragma unroll
                 for (int n2 = 0; n2 < 32; ++n2) r[n2] = pp[64 * n2];
             }
-        }
-
-        // ---- edge frames come through LDS; then window -----------------------------------------
-        if (!interior) {
+        } else {
+            // edge frames (overlapping the padding) come through LDS
             stage_edge_frame(X, a.pcm + ti.soff, t * a.hop - a.pad, ti.T, a.reflect, lane);
 #pragma unroll
             for (int n2 = 0; n2 < 32; ++n2) r[n2] = X[lane + 64 * n2];
+            raw_ok = false;
+            rn_ok = false;
         }
         if (WIN == IN_REGS) {
 #pragma unroll
@@ -454,11 +463,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         }
 
         have = have_n; ti = ti_n; t = t_n; slot = slot_n;
-        if (PREFETCH) {
-            interior = interior_n;
-#pragma unroll
-            for (int n2 = 0; n2 < 32; ++n2) r[n2] = rn[n2];
-        }
     }
     flush_max(runmax, cur_grp, a.gmax, lane);
 }

@@ -275,6 +275,7 @@ struct FrontVariant {
     int waves;
     int win, tw1;            // k2048::TableHome
     bool w64_regs, melw_lds;
+    int hopr;                // 0, or the hop_length / 64 the variant is built for
 };
 
 struct mfcc_plan {
@@ -312,44 +313,48 @@ namespace {
 
 // Front-end kernel variants: wavefronts per workgroup (one workgroup per CU; LDS-limited) and
 // where the per-lane constant tables live.  MFCC_HIP_VARIANT selects one for experiments.
-#define FRONT_VARIANT(W, WIN, TW1, W64R, MELW, PF, PW) \
-    {k_melspec_2048<W, WIN, TW1, W64R, MELW, PF, PW>, W, WIN, TW1, W64R, MELW}
+#define FRONT_VARIANT(W, WIN, TW1, W64R, MELW, HOPR, PW) \
+    {k_melspec_2048<W, WIN, TW1, W64R, MELW, HOPR, PW>, W, WIN, TW1, W64R, MELW, HOPR}
 using k2048::IN_GLOBAL;
 using k2048::IN_LDS;
 using k2048::IN_REGS;
+// hopr = 0 variants take any hop_length; hopr = 8 variants need hop_length = 512.
 const FrontVariant kFrontVariants[] = {
-    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, false, true, 0),   // 0: fallback, mel weights streamed
-    FRONT_VARIANT(12, IN_REGS, IN_LDS, true, true, true, 0),    // 1
-    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, true, true, 0),    // 2
-    FRONT_VARIANT(12, IN_REGS, IN_LDS, false, true, true, 0),   // 3
-    FRONT_VARIANT(8, IN_REGS, IN_LDS, true, true, true, 0),     // 4
-    FRONT_VARIANT(8, IN_LDS, IN_LDS, false, true, true, 0),     // 5
-    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, true, false, 0),   // 6: no prefetch
-    FRONT_VARIANT(14, IN_LDS, IN_LDS, false, true, false, 0),   // 7
-    FRONT_VARIANT(14, IN_GLOBAL, IN_GLOBAL, false, true, false, 0),  // 8
-    FRONT_VARIANT(15, IN_GLOBAL, IN_GLOBAL, false, true, false, 0),  // 9
-    FRONT_VARIANT(16, IN_GLOBAL, IN_GLOBAL, false, false, false, 0), // 10
-    FRONT_VARIANT(12, IN_GLOBAL, IN_LDS, false, true, true, 0),      // 11
+    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, false, 0, 0),  // 0: fallback, mel weights streamed
+    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, true, 0, 0),   // 1: any hop
+    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, true, 8, 0),   // 2: hop 512, samples reused in registers
+    FRONT_VARIANT(12, IN_REGS, IN_LDS, false, true, 8, 0),  // 3
+    FRONT_VARIANT(8, IN_REGS, IN_LDS, true, true, 8, 0),    // 4
+    FRONT_VARIANT(8, IN_LDS, IN_LDS, false, true, 8, 0),    // 5
+    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, false, 8, 0),  // 6: hop 512, mel weights streamed
 };
-// power != 2: same structure as variants 0 (mel weights streamed) and 2 (mel weights in LDS).
+// power != 2: same structure as variants 0 (mel weights streamed) and 1 (mel weights in LDS).
 const FrontVariant kFrontGeneralPower[] = {
-    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, false, true, 1),
-    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, true, true, 1),
+    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, false, 0, 1),
+    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, true, 0, 1),
 };
 constexpr int kNumFrontVariants = sizeof(kFrontVariants) / sizeof(kFrontVariants[0]);
-constexpr int kDefaultFrontVariant = 6;
 
 int select_variant(mfcc_plan* p) {
-    int v = kDefaultFrontVariant;
-    if (const char* e = std::getenv("MFCC_HIP_VARIANT")) v = std::atoi(e);
-    if (v < 0 || v >= kNumFrontVariants) return fail(MFCC_E_INVALID, "MFCC_HIP_VARIANT out of range");
     const int melw_floats = p->sm.total_rounds * 64;
     auto bytes = [&](int i) {
         const FrontVariant& f = kFrontVariants[i];
         return k2048::lds_bytes(f.waves, f.win, f.tw1, f.w64_regs, f.melw_lds ? melw_floats : 0);
     };
-    if (bytes(v) > (size_t)k2048::LDS_LIMIT) v = 0;  // mel weights too large for LDS: stream them
-    if (bytes(v) > (size_t)k2048::LDS_LIMIT) return fail(MFCC_E_UNSUPPORTED, "LDS budget exceeded");
+    auto usable = [&](int i) {
+        const FrontVariant& f = kFrontVariants[i];
+        return bytes(i) <= (size_t)k2048::LDS_LIMIT && (f.hopr == 0 || p->r.c.hop_length == 64 * f.hopr);
+    };
+    // default: reuse samples in registers when the hop allows it, mel weights in LDS when they fit
+    int v = -1;
+    for (int cand : {2, 6, 1, 0})
+        if (usable(cand)) { v = cand; break; }
+    if (const char* e = std::getenv("MFCC_HIP_VARIANT")) {
+        const int w = std::atoi(e);
+        if (w < 0 || w >= kNumFrontVariants) return fail(MFCC_E_INVALID, "MFCC_HIP_VARIANT out of range");
+        if (usable(w)) v = w;
+    }
+    if (v < 0) return fail(MFCC_E_UNSUPPORTED, "LDS budget exceeded");
     p->front = kFrontVariants[v];
     if (p->r.c.power != 2.0f) p->front = kFrontGeneralPower[p->front.melw_lds ? 1 : 0];
     p->variant = v;
