@@ -32,24 +32,49 @@ constexpr int TILE_FRAMES = 16;
 // ds_write_b64 of step 1 and the ds_read_b128 of step 2 are both bank-conflict free.
 constexpr int COL_STRIDE = 72;
 constexpr int XCH_FLOATS = (15 * COL_STRIDE + 70) * 2;   // 2300 floats per wavefront
-constexpr int SPECIAL_OFF = 1152;                 // float offset of the column-0 scratch
+// After step 2 the same region holds, per wavefront:
+//   the power spectrum in rows of 128 bins, 144 floats apart (the 16 floats of padding put the
+//   two halves of a merged ds_write2_b32 on disjoint banks): bin k at k + 16 (k >> 7)
+//   the column-0 scratch (4 rows of 24 complex)
+//   the mel cells: rows of 64 partial sums (MelJobs in host_tables.h), the last row for idle jobs
+#ifndef MFCC_AB_PROW
+#define MFCC_AB_PROW 144
+#endif
+#ifndef MFCC_AB_QUAD_ASM
+#define MFCC_AB_QUAD_ASM 1
+#endif
+constexpr int P_ROW = MFCC_AB_PROW;
+constexpr int P_END = 8 * P_ROW + 16;             // bin 1024 sits at 1152; reads may run on to here
+constexpr int SPECIAL_OFF = P_END;                // float offset of the column-0 scratch
 constexpr int SPECIAL_ROW = 24;                   // complex per kb row of that scratch
+constexpr int MCELL_OFF = SPECIAL_OFF + 4 * SPECIAL_ROW * 2;
+constexpr int MCELL_ROWS = (XCH_FLOATS - MCELL_OFF) / 64;   // 14, one of them for idle jobs
+static_assert(MCELL_ROWS >= 5, "per-wavefront LDS region too small");
+constexpr int MEL_J = 3;                          // quads (of 4 bins) per mel job
+constexpr int MEL_REG_JOBS = 4;                   // jobs per lane that are kept in registers
+#ifndef MFCC_AB_MEL_BATCH
+#define MFCC_AB_MEL_BATCH 2
+#endif
+constexpr int MEL_BATCH = MFCC_AB_MEL_BATCH;      // jobs whose reads are in flight together (2 or 4)
+constexpr int MEL_MAX_ROWS = 6;                   // cell rows per group of 64 filters
 constexpr int TW1_FLOATS = 15 * 64 * 2;
 constexpr int W64_STRIDE = 18;                    // complex per kb row (16 + 2 pad)
 constexpr int W64_FLOATS = 4 * W64_STRIDE * 2;
 constexpr int WIN_FLOATS = 2048;
 constexpr int LDS_LIMIT = 160 * 1024;
 constexpr int MAX_MEL_PASS = 4;                   // n_mels <= 256
-constexpr int MEL_CHUNK = 4;                      // ds_read_b128 pairs in flight per batch (mel)
+constexpr int MEL_CHUNK = 4;                      // generic kernel: ds_read_b128 pairs in flight
 
 enum TableHome { IN_LDS = 0, IN_REGS = 1, IN_GLOBAL = 2 };
 
 // LDS bytes of a variant: per-wavefront exchange regions, then the tables that live in LDS.
+// melw_floats: mel weights + job table (2 ints per job and lane) when they live in LDS, else 0
 constexpr size_t lds_bytes(int waves, int win, int tw1, bool w64_regs, int melw_floats) {
     return sizeof(float) * ((size_t)waves * XCH_FLOATS + (tw1 == IN_LDS ? TW1_FLOATS : 0) +
                             (w64_regs ? 0 : W64_FLOATS) + (win == IN_LDS ? WIN_FLOATS : 0) +
                             (size_t)melw_floats);
 }
+__host__ __device__ constexpr int p_index(int bin) { return bin + (P_ROW - 128) * (bin >> 7); }
 }  // namespace k2048
 
 struct __attribute__((aligned(32))) Tile {
@@ -80,16 +105,16 @@ struct FrontArgs {
     const float2* tw1;       // 15 x 64, scaled
     const float2* w64;       // 4 x 16
     const float2* tw128;     // 64
-    const float4* melw;      // (total_rounds / 4) x 64 quads of weights
-    const int32_t* mel_start;  // bin index (multiple of 4) each lane starts reading at
-    const int32_t* mel_filt;
-    const MelPass* mel_pass;
+    const float4* melw;      // (n_jobs * MEL_J) x 64 quads of weights
+    const int2* mel_jobs;    // n_jobs x 64: byte offsets, within the wavefront's LDS region, of
+                             // the job's first quad (.x) and of its cell (.y)
     float* mel_out;          // (rows, n_mels) or nullptr
     float* spec_out;         // (rows, 1025) or nullptr
     uint32_t* gmax;
-    int32_t n_pass;
+    int32_t n_jobs;
     int32_t n_mels;
-    int32_t total_rounds;
+    int32_t mel_rows[4];     // cell rows per group of 64 filters
+    int32_t mel_shared;      // the jobs of a filter add into one cell (LDS atomics)
     int32_t hop;
     int32_t pad;             // n_fft/2 if center else 0
     int32_t reflect;
@@ -109,6 +134,29 @@ __device__ __forceinline__ float quad_swap1(float v) {  // lane i <- lane i^1
                                                               0xF, 0xF, true));
 }
 
+// v[i] += s * (v[i] of the lane's quad partner), eight registers per call: one v_fmac_f32 with a
+// DPP source operand each (the compiler only forms v_mov_b32_dpp + v_fma_f32).  CTRL 2: partner
+// lane ^ 2, CTRL 1: partner lane ^ 1.  A DPP operand may not be read within two wait states of
+// the VALU instruction that wrote it; the leading s_nop covers whatever precedes the block.
+#define MFCC_DPP_FMAC8(PERM)                                                                       \
+    asm("s_nop 1\n\t"                                                                             \
+        "v_fmac_f32_dpp %0, %0, %8 " PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+        "v_fmac_f32_dpp %1, %1, %8 " PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+        "v_fmac_f32_dpp %2, %2, %8 " PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+        "v_fmac_f32_dpp %3, %3, %8 " PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+        "v_fmac_f32_dpp %4, %4, %8 " PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+        "v_fmac_f32_dpp %5, %5, %8 " PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+        "v_fmac_f32_dpp %6, %6, %8 " PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+        "v_fmac_f32_dpp %7, %7, %8 " PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1"               \
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]),     \
+          "+v"(v[7])                                                                               \
+        : "v"(s))
+template <int CTRL>
+__device__ __forceinline__ void quad_fmac8(float* v, float s) {
+    if (CTRL == 2) MFCC_DPP_FMAC8("quad_perm:[2,3,0,1]");
+    else MFCC_DPP_FMAC8("quad_perm:[1,0,3,2]");
+}
+
 // |X|^power from |X|^2.  PW = 0: power 2 (the reference's); PW = 1: any other power, decided at
 // run time (kept out of the power-2 instantiations: powf is ~200 instructions per call site).
 template <int PW>
@@ -123,6 +171,16 @@ __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t T) {
     int64_t m = i % period;
     if (m < 0) m += period;
     return m < T ? m : period - m;
+}
+
+// Wave-uniform read of a tile descriptor through the scalar cache (tiles are written by an
+// earlier kernel and never by this one).
+__device__ __forceinline__ Tile load_tile(const Tile* tiles, int idx) {
+    typedef const Tile __attribute__((address_space(4))) ConstTile;
+    const ConstTile* p = (const ConstTile*)(uintptr_t)(tiles + __builtin_amdgcn_readfirstlane(idx));
+    Tile t;
+    t.soff = p->soff; t.row0 = p->row0; t.T = p->T; t.f0 = p->f0; t.F = p->F; t.grp = p->grp;
+    return t;
 }
 
 __device__ __forceinline__ void flush_max(float runmax, int grp, uint32_t* gmax, int lane) {
@@ -176,12 +234,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     float* win_l = tab;
     if (WIN == IN_LDS) tab += WIN_FLOATS;
     float4* melw_l = reinterpret_cast<float4*>(tab);
+    int2* jobs_l = reinterpret_cast<int2*>(melw_l + a.n_jobs * MEL_J * 64);
 
     for (int i = tid; i < WAVES * XCH_FLOATS; i += THREADS) lds[i] = 0.0f;
     if (TW1 == IN_LDS) { for (int i = tid; i < 15 * 64; i += THREADS) tw1_l[i] = a.tw1[i]; }
     if (!W64_REGS) { if (tid < 64) w64_l[(tid >> 4) * W64_STRIDE + (tid & 15)] = a.w64[tid]; }
     if (WIN == IN_LDS) { for (int i = tid; i < 2048; i += THREADS) win_l[i] = a.window[i]; }
-    if (MELW_LDS) { for (int i = tid; i < a.total_rounds * 16; i += THREADS) melw_l[i] = a.melw[i]; }
+    if (MELW_LDS) {
+        for (int i = tid; i < a.n_jobs * MEL_J * 64; i += THREADS) melw_l[i] = a.melw[i];
+        for (int i = tid; i < a.n_jobs * 64; i += THREADS) jobs_l[i] = a.mel_jobs[i];
+    }
     __syncthreads();
 
     const int q = lane & 3, k2c = lane >> 2;
@@ -198,33 +260,30 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     }
     const float2 tw128 = a.tw128[lane];
 
+    // Quad DFT-4 signs.  Each butterfly is own + sign * partner (one v_fmac with a DPP operand),
+    // which leaves lanes 1..3 of the quad with their outputs negated; only |X|^2 is used.
     const float sgn1 = (q & 2) ? -1.0f : 1.0f;
-    const float sgn2 = (q & 1) ? -1.0f : 1.0f;
+    const float sgn2 = (q == 1 || q == 2) ? -1.0f : 1.0f;
     const bool lane3 = (q == 3);
     // exchange addressing (complex index c of column k2 lives at k2 * 72 + c + 2 * (c >> 4))
     const int xw_off = lane + 2 * (lane >> 4);                  // step-1 write, + k2 * COL_STRIDE
     const int y_off = lane + 4 * (lane >> 5);                   // column 0 as 128 reals
     const int xr_off = k2c * COL_STRIDE + 18 * q;               // step-2 read (complex index)
-    // power spectrum addressing: ka < 8 -> bin 128 ka + pb0; ka >= 8 -> bin 128 (15 - ka) + pb1
+    // power spectrum addressing (rows of 128 bins, P_ROW floats apart):
+    // ka < 8 -> bin 128 ka + pb0; ka >= 8 -> bin 128 (15 - ka) + pb1
     const int pb0 = 32 * kb + k2c;
     const int pb1 = 128 - 32 * kb - k2c;
     // column-0 scratch: C[j] at (j & 3) * SPECIAL_ROW + (j >> 2)
     const int sj = (lane & 3) * SPECIAL_ROW + (lane >> 2);
     const int sm = (((64 - lane) & 63) & 3) * SPECIAL_ROW + (((64 - lane) & 63) >> 2);
 
-    // per-lane mel work, loop-invariant: first bin, filter index; per pass: rounds, weight offset
-    int mel_st[MAX_MEL_PASS], mel_fi[MAX_MEL_PASS], mel_rounds[MAX_MEL_PASS], mel_roff[MAX_MEL_PASS];
+    const int n_jobs = a.n_jobs;
+    // jobs of this lane, kept in registers when there are at most MEL_REG_JOBS of them
+    int2 jobr[MEL_REG_JOBS];
 #pragma unroll
-    for (int p = 0; p < MAX_MEL_PASS; ++p) {
-        mel_st[p] = 0; mel_fi[p] = -1; mel_rounds[p] = 0; mel_roff[p] = 0;
-        if (p < a.n_pass) {
-            mel_st[p] = a.mel_start[p * 64 + lane];
-            mel_fi[p] = a.mel_filt[p * 64 + lane];
-            mel_rounds[p] = __builtin_amdgcn_readfirstlane(a.mel_pass[p].rounds);      // scalar
-            mel_roff[p] = __builtin_amdgcn_readfirstlane(a.mel_pass[p].round_off);
-        }
-    }
-
+    for (int j = 0; j < MEL_REG_JOBS; ++j) jobr[j] = a.mel_jobs[(j < n_jobs ? j : 0) * 64 + lane];
+    const int n_acc = (a.n_mels + 63) >> 6;          // groups of 64 filters
+    const int n_cell_rows = a.mel_rows[0] + a.mel_rows[1] + a.mel_rows[2] + a.mel_rows[3];
     float runmax = 0.0f;
     int cur_grp = -1;
     const int n_tiles = a.hdr->n_tiles;
@@ -235,98 +294,97 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     // different wavefronts do not overlap, so each sample leaves HBM once), and a wavefront
     // stays within one utterance for many frames (one atomicMax per utterance change).
     const int64_t n_slots = (int64_t)n_tiles * TILE_FRAMES;
-    const int64_t slot_stride = 1;
     const int64_t n_runs = (int64_t)gridDim.x * WAVES;
     const int64_t per_run = (n_slots + n_runs - 1) / n_runs;
     const int64_t run = (int64_t)blockIdx.x * WAVES + wave;
-    const int64_t slot_end = min(n_slots, (run + 1) * per_run);
+    const int64_t slot0 = run * per_run;
+    const int64_t slot_end = min(n_slots, slot0 + per_run);
 
-    Tile ti;           // current work
-    int t = 0;
-    int64_t slot = run * per_run;
-
-    // find the first valid slot at or after `s`; wave-uniform
-    auto next_valid = [&](int64_t s, Tile& o_ti, int& o_t, int64_t& o_slot) -> bool {
-        for (; s < slot_end; s += slot_stride) {
-            const Tile c = a.tiles[s >> 4];
-            const int tt = c.f0 + (int)(s & 15);
-            if (tt < c.F) { o_ti = c; o_t = tt; o_slot = s; return true; }
-        }
-        return false;
-    };
+    // Tile descriptors are read with scalar loads, one tile ahead of the frames being processed,
+    // so the frame loop never waits on them (a vector load here would make every frame wait for
+    // the previous frame's stores to be acknowledged).
+    int remaining = slot_end > slot0 ? (int)(slot_end - slot0) : 0;
+    int tix = (int)(slot0 >> 4), fr = (int)(slot0 & 15);
+    Tile ti = {}, ti_next = {};
+    if (remaining > 0) {
+        ti = load_tile(a.tiles, tix);
+        ti_next = load_tile(a.tiles, min(tix + 1, n_tiles - 1));
+    }
     auto is_interior = [&](const Tile& c, int tt) -> bool {
         const int start = tt * a.hop - a.pad;
         return start >= 0 && start + NFFT <= c.T;
     };
 
-    bool have = next_valid(slot, ti, t, slot);
     // HOPR > 0 (hop = 64 * HOPR): consecutive frames of a run share their rows n2 >= HOPR, so the
-    // unwindowed samples stay in registers, shift by HOPR rows per frame, and only the HOPR new
-    // rows are loaded -- requested one frame ahead.
+    // unwindowed samples stay in registers: once a frame has been windowed they shift down by
+    // HOPR rows and the HOPR new rows of the next frame are requested, a whole frame ahead.
     float raw[HOPR > 0 ? 32 : 1];
-    float rn[HOPR > 0 ? HOPR : 1];
-    bool raw_ok = false, rn_ok = false;
+    bool raw_ok = false;               // raw[] already holds the samples of the frame about to run
 
-    while (have) {
-        if (ti.grp != cur_grp) {
+    for (; remaining > 0; --remaining) {
+        const int t = ti.f0 + fr;
+        const bool valid = t < ti.F;        // the last tile of an utterance may be partly empty
+        // does the next slot of this run hold frame t + 1 of the same utterance?
+        const bool next_same = remaining > 1 &&
+            (fr < TILE_FRAMES - 1 ? t + 1 < ti.F : (ti_next.soff == ti.soff && ti_next.f0 == t + 1));
+        const Tile tc = ti;
+        if (++fr == TILE_FRAMES) {
+            fr = 0;
+            ++tix;
+            ti = ti_next;
+            ti_next = load_tile(a.tiles, min(tix + 1, n_tiles - 1));
+        }
+        if (!valid) continue;
+        if (tc.grp != cur_grp) {
             flush_max(runmax, cur_grp, a.gmax, lane);
-            cur_grp = ti.grp;
+            cur_grp = tc.grp;
             runmax = 0.0f;
         }
-        const int64_t row = ti.row0 + (t - ti.f0);
-        const bool interior = is_interior(ti, t);
-        Tile ti_n;
-        int t_n = 0;
-        int64_t slot_n = 0;
-        const bool have_n = next_valid(slot + slot_stride, ti_n, t_n, slot_n);
+        const int64_t row = tc.row0 + (t - tc.f0);
+        const bool interior = is_interior(tc, t);
 
-        // ---- samples --------------------------------------------------------------------------------
+        // ---- samples, window ----------------------------------------------------------------------
         float r[32];
-        if (interior) {
-            const float* pp = a.pcm + ti.soff + (t * a.hop - a.pad) + lane;
+        {
+            float* src = HOPR > 0 ? raw : r;
+            const float* pp = a.pcm + tc.soff + (t * a.hop - a.pad) + lane;
+            if (!interior) {
+                // edge frames (overlapping the padding) come through LDS
+                stage_edge_frame(X, a.pcm + tc.soff, t * a.hop - a.pad, tc.T, a.reflect, lane);
+#pragma unroll
+                for (int n2 = 0; n2 < 32; ++n2) src[n2] = X[lane + 64 * n2];
+                // leave nothing of the staged samples behind: the padding of the power-spectrum
+                // rows is read (with zero weights) by the mel stage and must stay finite
+#pragma unroll 1
+                for (int i = lane; i < XCH_FLOATS; i += 64) X[i] = 0.0f;
+            } else if (HOPR == 0 || !raw_ok) {
+#pragma unroll
+                for (int n2 = 0; n2 < 32; ++n2) src[n2] = pp[64 * n2];
+            }
+            if (WIN == IN_REGS) {
+#pragma unroll
+                for (int n2 = 0; n2 < 32; ++n2) r[n2] = src[n2] * win[n2];
+            } else {
+                float wv[32];
+#pragma unroll
+                for (int n2 = 0; n2 < 32; ++n2)
+                    wv[n2] = (WIN == IN_LDS) ? win_l[lane + 64 * n2] : a.window[lane + 64 * n2];
+                __builtin_amdgcn_sched_barrier(0);   // all table reads in flight before the first use
+#pragma unroll
+                for (int n2 = 0; n2 < 32; ++n2) r[n2] = src[n2] * wv[n2];
+            }
             if (HOPR > 0) {
-                if (raw_ok && rn_ok) {
+                raw_ok = interior && next_same && is_interior(tc, t + 1);
+                // (the shift is unconditional: when the next frame reloads everything it is dead)
 #pragma unroll
-                    for (int n2 = 0; n2 < 32 - HOPR; ++n2) raw[n2] = raw[n2 + HOPR];
-#pragma unroll
-                    for (int j = 0; j < HOPR; ++j) raw[32 - HOPR + j] = rn[j];
-                } else {
-#pragma unroll
-                    for (int n2 = 0; n2 < 32; ++n2) raw[n2] = pp[64 * n2];
-                }
-                raw_ok = true;
-                rn_ok = have_n && ti_n.soff == ti.soff && t_n == t + 1 && is_interior(ti_n, t_n);
-                if (rn_ok) {
+                for (int n2 = 0; n2 < 32 - HOPR; ++n2) raw[n2] = raw[n2 + HOPR];
+                if (raw_ok) {
                     const float* pn = pp + a.hop + 64 * (32 - HOPR);
 #pragma unroll
-                    for (int j = 0; j < HOPR; ++j) rn[j] = pn[64 * j];
+                    for (int j = 0; j < HOPR; ++j) raw[32 - HOPR + j] = pn[64 * j];
                 }
-                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this frame's work
-#pragma unroll
-                for (int n2 = 0; n2 < 32; ++n2) r[n2] = raw[n2];
-            } else {
-#pragma unroll
-                for (int n2 = 0; n2 < 32; ++n2) r[n2] = pp[64 * n2];
+                __builtin_amdgcn_sched_barrier(0);   // the prefetch is issued before the FFT starts
             }
-        } else {
-            // edge frames (overlapping the padding) come through LDS
-            stage_edge_frame(X, a.pcm + ti.soff, t * a.hop - a.pad, ti.T, a.reflect, lane);
-#pragma unroll
-            for (int n2 = 0; n2 < 32; ++n2) r[n2] = X[lane + 64 * n2];
-            raw_ok = false;
-            rn_ok = false;
-        }
-        if (WIN == IN_REGS) {
-#pragma unroll
-            for (int n2 = 0; n2 < 32; ++n2) r[n2] *= win[n2];
-        } else {
-            float wv[32];
-#pragma unroll
-            for (int n2 = 0; n2 < 32; ++n2)
-                wv[n2] = (WIN == IN_LDS) ? win_l[lane + 64 * n2] : a.window[lane + 64 * n2];
-            __builtin_amdgcn_sched_barrier(0);   // all table reads in flight before the first use
-#pragma unroll
-            for (int n2 = 0; n2 < 32; ++n2) r[n2] *= wv[n2];
         }
 
         // ---- step 1: real DFT-32 over n2, twiddle, exchange ------------------------------------
@@ -348,6 +406,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
 #pragma unroll
             for (int k2 = 1; k2 < 16; ++k2) {
                 fc::cmul(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
+                if (!(a.ablate & 32))
                 X2[k2 * COL_STRIDE + xw_off] = make_float2(ar[k2], ai[k2]);
             }
         }
@@ -374,15 +433,28 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
                 }
             }
             __builtin_amdgcn_sched_barrier(0);   // all exchange + twiddle reads in flight
+#if MFCC_AB_QUAD_ASM
+            quad_fmac8<2>(dr, sgn1); quad_fmac8<2>(dr + 8, sgn1);
+            quad_fmac8<2>(di, sgn1); quad_fmac8<2>(di + 8, sgn1);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float xr = fmaf(sgn1, dr[i], quad_swap2(dr[i]));
-                float xi = fmaf(sgn1, di[i], quad_swap2(di[i]));
-                const float yr = lane3 ? xi : xr;       // lane 3: multiply by -i
-                const float yi = lane3 ? -xr : xi;
-                dr[i] = fmaf(sgn2, yr, quad_swap1(yr));
-                di[i] = fmaf(sgn2, yi, quad_swap1(yi));
+                const float xr = dr[i], xi = di[i];
+                dr[i] = lane3 ? -xi : xr;               // lane 3 holds -(x1 - x3): multiply by +i
+                di[i] = lane3 ? xr : xi;
             }
+            quad_fmac8<1>(dr, sgn2); quad_fmac8<1>(dr + 8, sgn2);
+            quad_fmac8<1>(di, sgn2); quad_fmac8<1>(di + 8, sgn2);
+#else
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float xr = fmaf(quad_swap2(dr[i]), sgn1, dr[i]);
+                const float xi = fmaf(quad_swap2(di[i]), sgn1, di[i]);
+                const float yr = lane3 ? -xi : xr;
+                const float yi = lane3 ? xr : xi;
+                dr[i] = fmaf(quad_swap1(yr), sgn2, yr);
+                di[i] = fmaf(quad_swap1(yi), sgn2, yi);
+            }
+#endif
 #pragma unroll
             for (int m = 1; m < 16; ++m) fc::cmul(dr[m], di[m], w6[m].x, w6[m].y);
             fc::cfft16(dr, di);
@@ -392,7 +464,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         // All exchange reads of this wavefront are complete (data dependence above), so the
         // exchange region can be overwritten.  Column 0 goes to its scratch first so that its
         // round trip through LDS overlaps the regular power computation.
-        if (lane < 4) {
+        if (lane < 4 && !(a.ablate & 8)) {
             float2* S = reinterpret_cast<float2*>(X + SPECIAL_OFF) + kb * SPECIAL_ROW;
 #pragma unroll
             for (int ka = 0; ka < 16; ++ka)
@@ -404,8 +476,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             for (int ka = 0; ka < 16; ++ka) {
                 const float re = dr[fc::cfft16_pos(ka)], im = di[fc::cfft16_pos(ka)];
                 const float pw = apply_power<PW>(re * re + im * im, a.pw_mode, a.half_power);
-                if (ka < 8) X[pb0 + 128 * ka] = pw; else X[pb1 + 128 * (15 - ka)] = pw;
+                if (a.ablate & 4) continue;
+                if (ka < 8) X[pb0 + P_ROW * ka] = pw; else X[pb1 + P_ROW * (15 - ka)] = pw;
             }
+        }
+        if (a.mel_out) {
+            for (int c = 0; c < n_cell_rows; ++c) X[MCELL_OFF + 64 * c + lane] = 0.0f;
         }
         {
             // column 0: C = DFT-64 of c[r] = y[2r] + i y[2r+1]; Y[j] = E[j] + W_128^j O[j]
@@ -416,53 +492,110 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             float tr = cj.y + cm.y, ti_ = cm.x - cj.x;        // 2 O[j] = -i (C[j] - conj C[64-j])
             fc::cmul(tr, ti_, tw128.x, tw128.y);
             const float yr = er + tr, yi = ei + ti_;          // 2 Y[j]
-            X[16 * lane] = apply_power<PW>(0.25f * (yr * yr + yi * yi), a.pw_mode, a.half_power);
+            if (!(a.ablate & 16))
+            X[16 * lane + 16 * (lane >> 3)] =
+                apply_power<PW>(0.25f * (yr * yr + yi * yi), a.pw_mode, a.half_power);
             if (lane == 0) {
                 const float zr = er - tr, zi = ei - ti_;      // 2 Y[64] (real)
-                X[1024] = apply_power<PW>(0.25f * (zr * zr + zi * zi), a.pw_mode, a.half_power);
+                X[p_index(1024)] = apply_power<PW>(0.25f * (zr * zr + zi * zi), a.pw_mode, a.half_power);
             }
         }
 
         if (a.spec_out) {
             float* so = a.spec_out + row * NBIN;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) so[i * 64 + lane] = X[i * 64 + lane];
-            if (lane == 0) so[1024] = X[1024];
+            for (int i = 0; i < 16; ++i) so[i * 64 + lane] = X[i * 64 + 16 * (i >> 1) + lane];
+            if (lane == 0) so[1024] = X[p_index(1024)];
         }
 
-        // ---- sparse mel filterbank: lane = filter, four bins per read -----------------------------
+        // ---- sparse mel filterbank: n_jobs jobs per lane, MEL_J quads of four bins per job ------
+        // A job multiplies MEL_J consecutive quads of the power spectrum with its weights and
+        // writes the partial sum to its cell; a filter's output is the sum of its cells, and the
+        // outputs leave as coalesced rows.  (Filterbanks cut into more jobs per filter than
+        // there are cell rows share one cell per filter through LDS atomics, which one wavefront
+        // executes in program order, so that sum is deterministic too -- but slow.)
         if (a.mel_out && !(a.ablate & 1)) {
-            float* mo = a.mel_out + row * a.n_mels;
+            const int2* jp = (MELW_LDS ? jobs_l : a.mel_jobs) + lane;
+            const float4* wp = (MELW_LDS ? melw_l : a.melw) + lane;
+            const char* Xb = reinterpret_cast<const char*>(X);
+            if (n_jobs <= MEL_REG_JOBS) {
+                // all reads of MEL_BATCH jobs in flight at once (n_jobs >= 4 here means n_jobs == 4)
 #pragma unroll
-            for (int p = 0; p < MAX_MEL_PASS; ++p) {
-                if (p < a.n_pass) {
-                    const float4* wp = (MELW_LDS ? melw_l : a.melw) + (mel_roff[p] >> 2) * 64 + lane;
-                    const float4* pp = reinterpret_cast<const float4*>(X + mel_st[p]);
-                    float acc0 = 0.0f, acc1 = 0.0f;
-                    const int nq = mel_rounds[p] >> 2;
-                    for (int i = 0; i < nq; i += MEL_CHUNK) {
-                        float4 w[MEL_CHUNK], v[MEL_CHUNK];
+                for (int j = 0; j < MEL_REG_JOBS; j += MEL_BATCH) {
+                    if (j < n_jobs) {
+                        float4 w[MEL_BATCH][MEL_J], v[MEL_BATCH][MEL_J];
 #pragma unroll
-                        for (int j = 0; j < MEL_CHUNK; ++j) { w[j] = wp[(i + j) * 64]; v[j] = pp[i + j]; }
-                        __builtin_amdgcn_sched_barrier(0);   // 2 * MEL_CHUNK reads in flight
+                        for (int u = 0; u < MEL_BATCH; ++u) {
+                            const float4* pp = reinterpret_cast<const float4*>(Xb + jobr[j + u].x);
 #pragma unroll
-                        for (int j = 0; j < MEL_CHUNK; ++j) {
-                            acc0 = fmaf(w[j].x, v[j].x, acc0);
-                            acc1 = fmaf(w[j].y, v[j].y, acc1);
-                            acc0 = fmaf(w[j].z, v[j].z, acc0);
-                            acc1 = fmaf(w[j].w, v[j].w, acc1);
+                            for (int i = 0; i < MEL_J; ++i) {
+                                w[u][i] = wp[((j + u) * MEL_J + i) * 64];
+                                v[u][i] = pp[i];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < MEL_BATCH; ++u) {
+                            float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+                            for (int i = 0; i < MEL_J; ++i) {
+                                acc0 = fmaf(w[u][i].x, v[u][i].x, acc0);
+                                acc1 = fmaf(w[u][i].y, v[u][i].y, acc1);
+                                acc0 = fmaf(w[u][i].z, v[u][i].z, acc0);
+                                acc1 = fmaf(w[u][i].w, v[u][i].w, acc1);
+                            }
+                            float* acc_p = reinterpret_cast<float*>(const_cast<char*>(Xb) + jobr[j + u].y);
+                            if (!a.mel_shared) *acc_p = acc0 + acc1;
+                            else __hip_atomic_fetch_add(acc_p, acc0 + acc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         }
                     }
-                    const float acc = acc0 + acc1;
-                    if (mel_fi[p] >= 0) {
-                        mo[mel_fi[p]] = acc;
+                }
+            } else {
+            int2 job = jp[0];
+            for (int j = 0; j < n_jobs; ++j) {
+                const float4* pp = reinterpret_cast<const float4*>(Xb + job.x);
+                float* acc_p = reinterpret_cast<float*>(const_cast<char*>(Xb) + job.y);
+                float4 w[MEL_J], v[MEL_J];
+#pragma unroll
+                for (int i = 0; i < MEL_J; ++i) { w[i] = wp[(j * MEL_J + i) * 64]; v[i] = pp[i]; }
+                if (j + 1 < n_jobs) job = jp[(j + 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);   // 2 * MEL_J + 1 reads in flight
+                float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < MEL_J; ++i) {
+                    acc0 = fmaf(w[i].x, v[i].x, acc0);
+                    acc1 = fmaf(w[i].y, v[i].y, acc1);
+                    acc0 = fmaf(w[i].z, v[i].z, acc0);
+                    acc1 = fmaf(w[i].w, v[i].w, acc1);
+                }
+                if (!a.mel_shared) *acc_p = acc0 + acc1;
+                else __hip_atomic_fetch_add(acc_p, acc0 + acc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            }
+            float* mo = a.mel_out + row * a.n_mels;
+            const float* cells = X + MCELL_OFF + lane;
+#pragma unroll
+            for (int p = 0; p < MAX_MEL_PASS; ++p) {
+                if (p < n_acc) {
+                    const int f = 64 * p + lane;
+                    // all reads of the group in flight at once; rows past the group's last are
+                    // re-reads of that last row and do not enter the sum
+                    const int R = a.mel_rows[p];
+                    float v[MEL_MAX_ROWS];
+#pragma unroll
+                    for (int c = 0; c < MEL_MAX_ROWS; ++c) v[c] = cells[64 * min(c, R - 1)];
+                    float acc = v[0];
+#pragma unroll
+                    for (int c = 1; c < MEL_MAX_ROWS; ++c) acc += (c < R) ? v[c] : 0.0f;
+                    cells += 64 * R;
+                    if (f < a.n_mels) {
+                        mo[f] = acc;
                         runmax = fmaxf(runmax, acc);
                     }
                 }
             }
         }
 
-        have = have_n; ti = ti_n; t = t_n; slot = slot_n;
     }
     flush_max(runmax, cur_grp, a.gmax, lane);
 }

@@ -300,4 +300,135 @@ void build_sparse_mel(const std::vector<float>& basis, int n_mels, int n_bins, i
     }
 }
 
+namespace {
+struct MelJob {
+    int filt;    // filter
+    int seq;     // index among the filter's jobs
+    int quad;    // first quad, in units of 4 floats of the padded layout
+    int slack;   // the job may start up to this many quads earlier
+    int cell;    // (slot * 4 + group) * 16 + residue once placed, else -1
+    int shift;   // quads the job was moved down by
+};
+
+// Kuhn's matching of jobs to (slot, lane group, bank-group residue) cells.
+struct JobMatcher {
+    int n_slots;
+    std::vector<MelJob>* jobs;
+    std::vector<int> owner;  // per cell
+    bool try_assign(int i, std::vector<char>& seen) {
+        const MelJob& jb = (*jobs)[i];
+        for (int ds = 0; ds < n_slots; ++ds) {
+            const int s = (jb.seq + ds) % n_slots;   // a filter's jobs prefer different slots
+            for (int g = 0; g < 4; ++g)
+                for (int d = 0; d <= jb.slack && d <= jb.quad; ++d) {
+                    const int cell = (s * 4 + g) * 16 + (jb.quad - d) % 16;
+                    if (seen[cell]) continue;
+                    seen[cell] = 1;
+                    if (owner[cell] < 0 || try_assign(owner[cell], seen)) { owner[cell] = i; return true; }
+                }
+        }
+        return false;
+    }
+};
+}  // namespace
+
+void build_mel_jobs(const std::vector<float>& basis, int n_mels, int n_bins, int quads, int row_bins,
+                    int row_stride, int max_rows, int max_rows_per_group, MelJobs& out) {
+    const int J = quads;
+    const int pad_quads = (row_stride - row_bins) / 4;
+    auto addr = [&](int bin) { return bin + (row_stride - row_bins) * (bin / row_bins); };
+    std::vector<int> first(n_mels, 0), last(n_mels, -1);
+    std::vector<MelJob> jobs;
+    for (int m = 0; m < n_mels; ++m) {
+        int lo = -1, hi = -1;
+        for (int k = 0; k < n_bins; ++k)
+            if (basis[(size_t)m * n_bins + k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
+        if (lo < 0) continue;
+        first[m] = lo; last[m] = hi;
+        int seq = 0;
+        for (int r = lo / row_bins; r <= hi / row_bins; ++r) {
+            const int a = std::max(lo, r * row_bins), b = std::min(hi, (r + 1) * row_bins - 1);
+            const int t0 = addr(a) / 4, nq = addr(b) / 4 - t0 + 1, nj = (nq + J - 1) / J;
+            for (int i = 0; i < nj; ++i) {
+                const int slack = (i == nj - 1) ? std::min(J * nj - nq, pad_quads) : 0;
+                jobs.push_back(MelJob{m, seq++, t0 + J * i, slack, -1, 0});
+            }
+        }
+    }
+    // the kernel runs up to four jobs per lane as one batch: never fewer than four
+    const int n_slots = std::max(4, ((int)jobs.size() + 63) / 64);
+    JobMatcher mt{n_slots, &jobs, std::vector<int>((size_t)n_slots * 64, -1)};
+    std::vector<int> idx(jobs.size());
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return jobs[a].slack < jobs[b].slack; });
+    std::vector<int> unplaced;
+    for (int i : idx) {
+        std::vector<char> seen(mt.owner.size(), 0);
+        if (!mt.try_assign(i, seen)) unplaced.push_back(i);
+    }
+    // lanes: within a (slot, group) the matched jobs take the group's lanes in residue order;
+    // jobs the matching could not place fill the remaining lanes (and may bank-conflict)
+    out.n_jobs = n_slots;
+    out.quads = J;
+    out.at.assign((size_t)n_slots * 64, 0);
+    out.cell.assign((size_t)n_slots * 64, 0);
+    out.w.assign((size_t)n_slots * J * 64 * 4, 0.0f);
+    out.max_read = 0;
+    out.bank_conflicts = (int)unplaced.size();
+    // cell rows: a filter cut into n jobs needs n rows in its group of 64 filters
+    std::vector<int> n_of(n_mels, 0);
+    for (const MelJob& jb : jobs) n_of[jb.filt] = std::max(n_of[jb.filt], jb.seq + 1);
+    const int n_groups = (n_mels + 63) / 64;
+    out.n_rows = 0;
+    for (int p = 0; p < 4; ++p) {
+        out.rows[p] = 0;
+        if (p >= n_groups) continue;
+        for (int f = 64 * p; f < std::min(n_mels, 64 * p + 64); ++f) out.rows[p] = std::max(out.rows[p], n_of[f]);
+        out.rows[p] = std::max(out.rows[p], 1);
+        out.n_rows += out.rows[p];
+    }
+    out.shared = out.n_rows > max_rows;
+    for (int p = 0; p < 4; ++p) out.shared = out.shared || out.rows[p] > max_rows_per_group;
+    if (out.shared) {
+        out.n_rows = n_groups;
+        for (int p = 0; p < n_groups; ++p) out.rows[p] = 1;
+    }
+    std::vector<int> row0(5, 0);
+    for (int p = 0; p < 4; ++p) row0[p + 1] = row0[p] + out.rows[p];
+    for (int s = 0; s < n_slots; ++s)
+        for (int l = 0; l < 64; ++l) out.cell[s * 64 + l] = out.n_rows * 64 + l;
+    std::vector<int> job_slot(jobs.size(), -1), job_lane(jobs.size(), -1);
+    size_t next_unplaced = 0;
+    for (int s = 0; s < n_slots; ++s)
+        for (int g = 0; g < 4; ++g) {
+            int j = 0;
+            for (int res = 0; res < 16; ++res) {
+                const int i = mt.owner[(s * 4 + g) * 16 + res];
+                if (i < 0) continue;
+                jobs[i].shift = ((jobs[i].quad - res) % 16 + 16) % 16;
+                job_slot[i] = s; job_lane[i] = kB128Groups[g][j++];
+            }
+            for (; j < 16 && next_unplaced < unplaced.size(); ++j) {
+                const int i = unplaced[next_unplaced++];
+                jobs[i].shift = 0;
+                job_slot[i] = s; job_lane[i] = kB128Groups[g][j];
+            }
+        }
+    std::vector<char> done((size_t)n_mels * n_bins, 0);
+    for (size_t i = 0; i < jobs.size(); ++i) {      // in filter order, a filter's jobs in sequence
+        const MelJob& jb = jobs[i];
+        const int s = job_slot[i], l = job_lane[i];
+        const int at = 4 * (jb.quad - jb.shift);
+        out.at[s * 64 + l] = at;
+        out.cell[s * 64 + l] = (row0[jb.filt / 64] + (out.shared ? 0 : jb.seq)) * 64 + (jb.filt & 63);
+        out.max_read = std::max(out.max_read, at + 4 * J - 1);
+        for (int k = first[jb.filt]; k <= last[jb.filt]; ++k) {
+            const int rel = addr(k) - at;
+            if (rel < 0 || rel >= 4 * J || done[(size_t)jb.filt * n_bins + k]) continue;
+            done[(size_t)jb.filt * n_bins + k] = 1;
+            out.w[((size_t)(s * J + rel / 4) * 64 + l) * 4 + (rel & 3)] = basis[(size_t)jb.filt * n_bins + k];
+        }
+    }
+}
+
 }  // namespace mfcc_host

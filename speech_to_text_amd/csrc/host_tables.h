@@ -47,4 +47,36 @@ struct SparseMel {
 // chunk_quads: rounds[p] / 4 is padded to a multiple of this.
 void build_sparse_mel(const std::vector<float>& basis, int n_mels, int n_bins, int chunk_quads, SparseMel& s);
 
+// Load-balanced packing of the mel filterbank for the 2048-point kernel.
+// The power spectrum lives in rows of row_bins bins, row r starting at float r * row_stride
+// (row_stride - row_bins floats of padding after each row).  Every filter's support is cut at
+// the row boundaries and then into jobs of `quads` consecutive 4-bin quads; each lane of the
+// wavefront runs n_jobs >= 4 jobs per frame.  Job j of lane l:
+//   at[j*64+l]    float index of the job's first quad (a multiple of 4) in the padded layout
+//   cell[j*64+l]  where the job's partial sum goes, in floats from the start of the cell area
+//   w[((j*quads + i)*64 + l)*4 + c]   weight of bin c of quad i
+// Cell area: for each group p of 64 filters, rows[p] rows of 64 cells; filter f = 64 p + x owns
+// cell x of each of its group's rows.  If no filter is cut into more than max_rows jobs in total
+// over the groups (sum of rows[p] <= max_rows, each rows[p] <= max_rows_per_group), every job
+// has a cell of its own and the
+// filter's output is the sum of its cells (cells no job writes must read as zero); otherwise
+// `shared` is set, rows[p] = 1 and the jobs of a filter add into one cell.  Idle jobs (all
+// weights zero) write to row sum(rows), cell l.
+// Jobs are dealt to (job slot, lane) so that the 16 lanes a ds_read_b128 services together read
+// from distinct LDS bank groups wherever the filter geometry allows it.
+struct MelJobs {
+    int n_jobs = 0;
+    int quads = 0;
+    std::vector<int32_t> at;
+    std::vector<int32_t> cell;
+    std::vector<float> w;
+    int rows[4] = {0, 0, 0, 0};
+    int n_rows = 0;         // sum of rows[]
+    bool shared = false;
+    int max_read = 0;       // largest float index any job reads
+    int bank_conflicts = 0; // jobs that could not be given a conflict-free (slot, lane)
+};
+void build_mel_jobs(const std::vector<float>& basis, int n_mels, int n_bins, int quads, int row_bins,
+                    int row_stride, int max_rows, int max_rows_per_group, MelJobs& out);
+
 }  // namespace mfcc_host

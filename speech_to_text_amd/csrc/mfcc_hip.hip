@@ -286,7 +286,8 @@ struct mfcc_plan {
     bool fast2048 = false;
     int variant = 0;
     size_t front_lds_bytes = 0;
-    mfcc_host::SparseMel sm;
+    mfcc_host::SparseMel sm;       // generic kernel: lane = filter
+    mfcc_host::MelJobs mj;         // 2048-point kernel: balanced jobs
     int n_rt = 0, n_mels_pad = 0;
     float ref_db = 0.0f;
     // device tables
@@ -298,6 +299,7 @@ struct mfcc_plan {
     int32_t* d_mel_start = nullptr;
     int32_t* d_mel_filt = nullptr;
     MelPass* d_mel_pass = nullptr;
+    int2* d_mel_jobs = nullptr;
     float* d_dct_frag = nullptr;
     float* d_lifter = nullptr;
     float* d_dfrag = nullptr;
@@ -327,6 +329,9 @@ const FrontVariant kFrontVariants[] = {
     FRONT_VARIANT(8, IN_REGS, IN_LDS, true, true, 8, 0),    // 4
     FRONT_VARIANT(8, IN_LDS, IN_LDS, false, true, 8, 0),    // 5
     FRONT_VARIANT(12, IN_LDS, IN_LDS, false, false, 8, 0),  // 6: hop 512, mel weights streamed
+    FRONT_VARIANT(12, IN_LDS, IN_LDS, true, true, 0, 0),    // 7: step-2 twiddles in registers
+    FRONT_VARIANT(12, IN_REGS, IN_LDS, false, true, 0, 0),  // 8: window in registers
+    FRONT_VARIANT(12, IN_REGS, IN_LDS, true, true, 0, 0),   // 9: both
 };
 // power != 2: same structure as variants 0 (mel weights streamed) and 1 (mel weights in LDS).
 const FrontVariant kFrontGeneralPower[] = {
@@ -336,7 +341,7 @@ const FrontVariant kFrontGeneralPower[] = {
 constexpr int kNumFrontVariants = sizeof(kFrontVariants) / sizeof(kFrontVariants[0]);
 
 int select_variant(mfcc_plan* p) {
-    const int melw_floats = p->sm.total_rounds * 64;
+    const int melw_floats = (int)p->mj.w.size() + 2 * 64 * p->mj.n_jobs;   // weights + job table
     auto bytes = [&](int i) {
         const FrontVariant& f = kFrontVariants[i];
         return k2048::lds_bytes(f.waves, f.win, f.tw1, f.w64_regs, f.melw_lds ? melw_floats : 0);
@@ -510,9 +515,17 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         delete p;
         return fail(MFCC_E_UNSUPPORTED, "n_mels > 256 is not supported");
     }
-    if (p->fast2048 && p->sm.max_read >= k2048::XCH_FLOATS) {
-        delete p;
-        return fail(MFCC_E_UNSUPPORTED, "mel filter support too wide for the LDS staging region");
+    std::vector<int2> jobs;
+    if (p->fast2048) {
+        mfcc_host::build_mel_jobs(basis, r.c.n_mels, r.n_bins, k2048::MEL_J, 128, k2048::P_ROW,
+                                  k2048::MCELL_ROWS - 1, k2048::MEL_MAX_ROWS, p->mj);
+        if (p->mj.max_read >= k2048::P_END) {
+            delete p;
+            return fail(MFCC_E_UNSUPPORTED, "mel job reads past the power-spectrum rows");
+        }
+        jobs.resize(p->mj.at.size());
+        for (size_t i = 0; i < jobs.size(); ++i)
+            jobs[i] = make_int2(4 * p->mj.at[i], 4 * (k2048::MCELL_OFF + p->mj.cell[i]));
     }
     std::vector<float> dfrag;
     if (!p->fast2048) {
@@ -566,11 +579,13 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
     if (rc == MFCC_OK) rc = upload(w64, &p->d_w64);
     if (rc == MFCC_OK) rc = upload(tw128, &p->d_tw128);
     if (rc == MFCC_OK) {
-        std::vector<float4> w4(p->sm.w.size() / 4);
+        const std::vector<float>& w = p->fast2048 ? p->mj.w : p->sm.w;
+        std::vector<float4> w4(w.size() / 4);
         for (size_t i = 0; i < w4.size(); ++i)
-            w4[i] = make_float4(p->sm.w[4 * i], p->sm.w[4 * i + 1], p->sm.w[4 * i + 2], p->sm.w[4 * i + 3]);
+            w4[i] = make_float4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
         rc = upload(w4, &p->d_melw);
     }
+    if (rc == MFCC_OK) rc = upload(jobs, &p->d_mel_jobs);
     if (rc == MFCC_OK) rc = upload(p->sm.start, &p->d_mel_start);
     if (rc == MFCC_OK) rc = upload(p->sm.filt, &p->d_mel_filt);
     if (rc == MFCC_OK) rc = upload(passes, &p->d_mel_pass);
@@ -592,7 +607,8 @@ void mfcc_plan_destroy(mfcc_plan* p) {
     if (!p) return;
     (void)hipFree(p->d_window); (void)hipFree(p->d_tw1); (void)hipFree(p->d_w64);
     (void)hipFree(p->d_tw128); (void)hipFree(p->d_melw); (void)hipFree(p->d_mel_start);
-    (void)hipFree(p->d_mel_filt); (void)hipFree(p->d_mel_pass); (void)hipFree(p->d_dct_frag);
+    (void)hipFree(p->d_mel_filt); (void)hipFree(p->d_mel_pass); (void)hipFree(p->d_mel_jobs);
+    (void)hipFree(p->d_dct_frag);
     (void)hipFree(p->d_lifter); (void)hipFree(p->d_dfrag);
     for (int i = 0; i < 3; ++i) if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
     delete p;
@@ -647,17 +663,17 @@ static int launch_front(const mfcc_plan* plan, const float* d_pcm, const int64_t
     FrontArgs fa;
     fa.pcm = d_pcm; fa.tiles = tiles; fa.hdr = hdr;
     fa.window = plan->d_window; fa.tw1 = plan->d_tw1; fa.w64 = plan->d_w64; fa.tw128 = plan->d_tw128;
-    fa.melw = plan->d_melw; fa.mel_start = plan->d_mel_start; fa.mel_filt = plan->d_mel_filt;
-    fa.mel_pass = plan->d_mel_pass;
+    fa.melw = plan->d_melw; fa.mel_jobs = plan->d_mel_jobs;
     fa.mel_out = mel_out; fa.spec_out = spec_out; fa.gmax = gmax;
-    fa.n_pass = plan->sm.n_pass; fa.n_mels = plan->r.c.n_mels;
+    fa.n_jobs = plan->mj.n_jobs; fa.n_mels = plan->r.c.n_mels;
+    fa.mel_shared = plan->mj.shared ? 1 : 0;
+    for (int i = 0; i < 4; ++i) fa.mel_rows[i] = plan->mj.rows[i];
     fa.hop = plan->r.c.hop_length;
     fa.pad = plan->r.c.center ? plan->r.c.n_fft / 2 : 0;
     fa.reflect = plan->r.c.pad_mode == MFCC_PAD_REFLECT;
     fa.ablate = std::getenv("MFCC_HIP_ABLATE") ? std::atoi(std::getenv("MFCC_HIP_ABLATE")) : 0;
     fa.pw_mode = plan->r.c.power == 2.0f ? 0 : (plan->r.c.power == 1.0f ? 1 : 2);
     fa.half_power = 0.5f * plan->r.c.power;
-    fa.total_rounds = plan->sm.total_rounds;
     const FrontVariant& fv = plan->front;
     const int64_t wg_needed = (L.ub_tiles * TILE_FRAMES + fv.waves - 1) / fv.waves;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(wg_needed, plan->n_cu));

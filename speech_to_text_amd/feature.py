@@ -255,6 +255,8 @@ def melspectrogram(*, y=None, sr=22050, device=None, validate=True, **kwargs) ->
     y = _as_float_array(y)
     if validate:
         _valid_audio(y)
+    # no DCT here: keep the (unused) n_mfcc within [1, n_mels] so small filterbanks are accepted
+    kwargs.setdefault("n_mfcc", min(20, int(kwargs.get("n_mels", 128))))
     config = make_config(sr=sr, **kwargs)
     chans, lead = _channels_of(y)
     out, fo = _run_batch(chans, config, groups=None, device=device, what="melspectrogram")

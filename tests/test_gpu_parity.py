@@ -53,6 +53,9 @@ def test_reference_default_one_utterance(S):
     dict(n_fft=2048, hop_length=512, window="hamming"),
     dict(n_fft=2048, hop_length=512, power=1.0),
     dict(n_fft=2048, hop_length=512, mel_norm=None, n_mels=40),
+    dict(n_fft=2048, hop_length=512, n_mels=10),                 # wide filters: shared mel cells
+    dict(n_fft=2048, hop_length=256, n_mels=256, sr=44100),      # four groups of 64 filters
+    dict(n_fft=2048, hop_length=512, n_mels=1),
     dict(n_fft=400, hop_length=160, n_mels=80, sr=16000),
     dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, sr=16000),
     dict(n_fft=1024, hop_length=256),
