@@ -15,8 +15,9 @@
 //          W_64^(m kb), 16-point DFT over m (output ka) -> X[128 ka + 32 kb + k2c];
 //          ka >= 8 are the mirror images of bins 17..31 mod 32
 //  column 0 is post-processed as a 128-point real DFT -> bins 16 j, j = 0..64
-//  mel     the power spectrum is written to the wavefront's LDS region in natural bin order;
-//          lane = filter, each lane reads its filter's contiguous bins four at a time
+//  mel     the power spectrum is written to the wavefront's LDS region in bin order (rows of 64
+//          bins); every lane runs the same number of jobs, each a dot product of 12 consecutive
+//          bins with one filter's weights, and each filter's partial sums are added up
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -33,22 +34,21 @@ constexpr int TILE_FRAMES = 16;
 constexpr int COL_STRIDE = 72;
 constexpr int XCH_FLOATS = (15 * COL_STRIDE + 70) * 2;   // 2300 floats per wavefront
 // After step 2 the same region holds, per wavefront:
-//   the power spectrum in rows of 128 bins, 144 floats apart (the 16 floats of padding put the
-//   two halves of a merged ds_write2_b32 on disjoint banks): bin k at k + 16 (k >> 7)
+//   the power spectrum in rows of 64 bins, 80 floats apart: bin k at k + 16 (k >> 6).  With the
+//   16 floats of padding the 64 lanes of one power-spectrum store (bins 32 kb + k2c + 128 ka)
+//   hit 64 different banks.
 //   the column-0 scratch (4 rows of 24 complex)
 //   the mel cells: rows of 64 partial sums (MelJobs in host_tables.h), the last row for idle jobs
-#ifndef MFCC_AB_PROW
-#define MFCC_AB_PROW 144
-#endif
 #ifndef MFCC_AB_QUAD_ASM
 #define MFCC_AB_QUAD_ASM 1
 #endif
-constexpr int P_ROW = MFCC_AB_PROW;
-constexpr int P_END = 8 * P_ROW + 16;             // bin 1024 sits at 1152; reads may run on to here
+constexpr int P_ROW_BINS = 64;
+constexpr int P_ROW = 80;
+constexpr int P_END = 16 * P_ROW + 16;            // bin 1024 sits at 1280; reads may run on to here
 constexpr int SPECIAL_OFF = P_END;                // float offset of the column-0 scratch
 constexpr int SPECIAL_ROW = 24;                   // complex per kb row of that scratch
 constexpr int MCELL_OFF = SPECIAL_OFF + 4 * SPECIAL_ROW * 2;
-constexpr int MCELL_ROWS = (XCH_FLOATS - MCELL_OFF) / 64;   // 14, one of them for idle jobs
+constexpr int MCELL_ROWS = (XCH_FLOATS - MCELL_OFF) / 64;   // 12, one of them for idle jobs
 static_assert(MCELL_ROWS >= 5, "per-wavefront LDS region too small");
 constexpr int MEL_J = 3;                          // quads (of 4 bins) per mel job
 constexpr int MEL_REG_JOBS = 4;                   // jobs per lane that are kept in registers
@@ -56,7 +56,7 @@ constexpr int MEL_REG_JOBS = 4;                   // jobs per lane that are kept
 #define MFCC_AB_MEL_BATCH 2
 #endif
 constexpr int MEL_BATCH = MFCC_AB_MEL_BATCH;      // jobs whose reads are in flight together (2 or 4)
-constexpr int MEL_MAX_ROWS = 6;                   // cell rows per group of 64 filters
+constexpr int MEL_MAX_ROWS = 4;                   // cell rows per group of 64 filters
 constexpr int TW1_FLOATS = 15 * 64 * 2;
 constexpr int W64_STRIDE = 18;                    // complex per kb row (16 + 2 pad)
 constexpr int W64_FLOATS = 4 * W64_STRIDE * 2;
@@ -74,7 +74,7 @@ constexpr size_t lds_bytes(int waves, int win, int tw1, bool w64_regs, int melw_
                             (w64_regs ? 0 : W64_FLOATS) + (win == IN_LDS ? WIN_FLOATS : 0) +
                             (size_t)melw_floats);
 }
-__host__ __device__ constexpr int p_index(int bin) { return bin + (P_ROW - 128) * (bin >> 7); }
+__host__ __device__ constexpr int p_index(int bin) { return bin + (P_ROW - P_ROW_BINS) * (bin >> 6); }
 }  // namespace k2048
 
 struct __attribute__((aligned(32))) Tile {
@@ -107,14 +107,16 @@ struct FrontArgs {
     const float2* tw128;     // 64
     const float4* melw;      // (n_jobs * MEL_J) x 64 quads of weights
     const int2* mel_jobs;    // n_jobs x 64: byte offsets, within the wavefront's LDS region, of
-                             // the job's first quad (.x) and of its cell (.y)
+                             // the job's first quad (.x) and of its cell (.y); bit 0 of .y: the
+                             // job continues the chain of the previous slot
     float* mel_out;          // (rows, n_mels) or nullptr
     float* spec_out;         // (rows, 1025) or nullptr
     uint32_t* gmax;
     int32_t n_jobs;
     int32_t n_mels;
     int32_t mel_rows[4];     // cell rows per group of 64 filters
-    int32_t mel_shared;      // the jobs of a filter add into one cell (LDS atomics)
+    uint32_t mel_zero_rows;  // cell rows to clear before each frame's jobs
+    int32_t mel_shared;      // the chains of a filter add into one cell (LDS atomics)
     int32_t hop;
     int32_t pad;             // n_fft/2 if center else 0
     int32_t reflect;
@@ -242,7 +244,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     if (WIN == IN_LDS) { for (int i = tid; i < 2048; i += THREADS) win_l[i] = a.window[i]; }
     if (MELW_LDS) {
         for (int i = tid; i < a.n_jobs * MEL_J * 64; i += THREADS) melw_l[i] = a.melw[i];
-        for (int i = tid; i < a.n_jobs * 64; i += THREADS) jobs_l[i] = a.mel_jobs[i];
+        if (a.n_jobs <= MEL_REG_JOBS) {
+            // short job lists: one uint4 per lane, a job per component (first quad in the low
+            // half, cell and chain bit in the high half), fetched with one read per frame
+            if (tid < 64) {
+                uint32_t pk[MEL_REG_JOBS];
+#pragma unroll
+                for (int j = 0; j < MEL_REG_JOBS; ++j) {
+                    const int2 jb = a.mel_jobs[(j < a.n_jobs ? j : 0) * 64 + tid];
+                    pk[j] = (uint32_t)jb.x | ((uint32_t)jb.y << 16);
+                }
+                reinterpret_cast<uint4*>(jobs_l)[tid] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+        } else {
+            for (int i = tid; i < a.n_jobs * 64; i += THREADS) jobs_l[i] = a.mel_jobs[i];
+        }
     }
     __syncthreads();
 
@@ -269,21 +285,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     const int xw_off = lane + 2 * (lane >> 4);                  // step-1 write, + k2 * COL_STRIDE
     const int y_off = lane + 4 * (lane >> 5);                   // column 0 as 128 reals
     const int xr_off = k2c * COL_STRIDE + 18 * q;               // step-2 read (complex index)
-    // power spectrum addressing (rows of 128 bins, P_ROW floats apart):
-    // ka < 8 -> bin 128 ka + pb0; ka >= 8 -> bin 128 (15 - ka) + pb1
-    const int pb0 = 32 * kb + k2c;
-    const int pb1 = 128 - 32 * kb - k2c;
+    // power spectrum addressing: ka < 8 -> bin 128 ka + 32 kb + k2c; ka >= 8 -> its mirror image
+    // bin 128 (15 - ka) + 128 - 32 kb - k2c (k2c > 0 there); 128 bins = 2 rows = 2 P_ROW floats
+    const int pb0 = p_index(32 * kb + k2c);
+    const int pb1 = p_index(128 - 32 * kb - k2c);
     // column-0 scratch: C[j] at (j & 3) * SPECIAL_ROW + (j >> 2)
     const int sj = (lane & 3) * SPECIAL_ROW + (lane >> 2);
     const int sm = (((64 - lane) & 63) & 3) * SPECIAL_ROW + (((64 - lane) & 63) >> 2);
 
     const int n_jobs = a.n_jobs;
-    // jobs of this lane, kept in registers when there are at most MEL_REG_JOBS of them
-    int2 jobr[MEL_REG_JOBS];
-#pragma unroll
-    for (int j = 0; j < MEL_REG_JOBS; ++j) jobr[j] = a.mel_jobs[(j < n_jobs ? j : 0) * 64 + lane];
     const int n_acc = (a.n_mels + 63) >> 6;          // groups of 64 filters
-    const int n_cell_rows = a.mel_rows[0] + a.mel_rows[1] + a.mel_rows[2] + a.mel_rows[3];
     float runmax = 0.0f;
     int cur_grp = -1;
     const int n_tiles = a.hdr->n_tiles;
@@ -321,6 +332,42 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     float raw[HOPR > 0 ? 32 : 1];
     bool raw_ok = false;               // raw[] already holds the samples of the frame about to run
 
+    // Mel outputs of a frame: each group's cell rows summed and stored as one coalesced row.
+    const float* cell0 = X + MCELL_OFF + lane;
+    auto collect_outputs = [&](int64_t row) {
+        const float* cells = cell0;
+        float outv[MAX_MEL_PASS];
+#pragma unroll
+        for (int p = 0; p < MAX_MEL_PASS; ++p) {
+            outv[p] = 0.0f;
+            if (p < n_acc) {
+                // rows of the group: nested so that all reads are issued before the first add
+                const int R = a.mel_rows[p];
+                float s0 = cells[0];
+                if (R > 1) {
+                    const float s1 = cells[64];
+                    if (R > 2) {
+                        const float s2 = cells[128];
+                        if (R > 3) s0 += cells[192];
+                        s0 += s2;
+                    }
+                    s0 += s1;
+                }
+                outv[p] = s0;
+                cells += 64 * R;
+            }
+        }
+        float* mo = a.mel_out + row * a.n_mels;
+#pragma unroll
+        for (int p = 0; p < MAX_MEL_PASS; ++p) {
+            const int f = 64 * p + lane;
+            if (p < n_acc && f < a.n_mels) {
+                mo[f] = outv[p];
+                runmax = fmaxf(runmax, outv[p]);
+            }
+        }
+    };
+
     for (; remaining > 0; --remaining) {
         const int t = ti.f0 + fr;
         const bool valid = t < ti.F;        // the last tile of an utterance may be partly empty
@@ -335,13 +382,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             ti_next = load_tile(a.tiles, min(tix + 1, n_tiles - 1));
         }
         if (!valid) continue;
+        const bool interior = is_interior(tc, t);
         if (tc.grp != cur_grp) {
             flush_max(runmax, cur_grp, a.gmax, lane);
             cur_grp = tc.grp;
             runmax = 0.0f;
         }
         const int64_t row = tc.row0 + (t - tc.f0);
-        const bool interior = is_interior(tc, t);
 
         // ---- samples, window ----------------------------------------------------------------------
         float r[32];
@@ -406,7 +453,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
 #pragma unroll
             for (int k2 = 1; k2 < 16; ++k2) {
                 fc::cmul(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
-                if (!(a.ablate & 32))
                 X2[k2 * COL_STRIDE + xw_off] = make_float2(ar[k2], ai[k2]);
             }
         }
@@ -464,7 +510,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         // All exchange reads of this wavefront are complete (data dependence above), so the
         // exchange region can be overwritten.  Column 0 goes to its scratch first so that its
         // round trip through LDS overlaps the regular power computation.
-        if (lane < 4 && !(a.ablate & 8)) {
+        if (lane < 4) {
             float2* S = reinterpret_cast<float2*>(X + SPECIAL_OFF) + kb * SPECIAL_ROW;
 #pragma unroll
             for (int ka = 0; ka < 16; ++ka)
@@ -476,12 +522,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             for (int ka = 0; ka < 16; ++ka) {
                 const float re = dr[fc::cfft16_pos(ka)], im = di[fc::cfft16_pos(ka)];
                 const float pw = apply_power<PW>(re * re + im * im, a.pw_mode, a.half_power);
-                if (a.ablate & 4) continue;
-                if (ka < 8) X[pb0 + P_ROW * ka] = pw; else X[pb1 + P_ROW * (15 - ka)] = pw;
+                if (ka < 8) X[pb0 + 2 * P_ROW * ka] = pw; else X[pb1 + 2 * P_ROW * (15 - ka)] = pw;
             }
         }
         if (a.mel_out) {
-            for (int c = 0; c < n_cell_rows; ++c) X[MCELL_OFF + 64 * c + lane] = 0.0f;
+            for (uint32_t m = a.mel_zero_rows; m; m &= m - 1)
+                X[MCELL_OFF + 64 * __builtin_ctz(m) + lane] = 0.0f;
         }
         {
             // column 0: C = DFT-64 of c[r] = y[2r] + i y[2r+1]; Y[j] = E[j] + W_128^j O[j]
@@ -492,8 +538,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             float tr = cj.y + cm.y, ti_ = cm.x - cj.x;        // 2 O[j] = -i (C[j] - conj C[64-j])
             fc::cmul(tr, ti_, tw128.x, tw128.y);
             const float yr = er + tr, yi = ei + ti_;          // 2 Y[j]
-            if (!(a.ablate & 16))
-            X[16 * lane + 16 * (lane >> 3)] =
+            X[16 * lane + 16 * (lane >> 2)] =
                 apply_power<PW>(0.25f * (yr * yr + yi * yi), a.pw_mode, a.half_power);
             if (lane == 0) {
                 const float zr = er - tr, zi = ei - ti_;      // 2 Y[64] (real)
@@ -504,62 +549,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         if (a.spec_out) {
             float* so = a.spec_out + row * NBIN;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) so[i * 64 + lane] = X[i * 64 + 16 * (i >> 1) + lane];
+            for (int i = 0; i < 16; ++i) so[i * 64 + lane] = X[i * P_ROW + lane];
             if (lane == 0) so[1024] = X[p_index(1024)];
         }
 
         // ---- sparse mel filterbank: n_jobs jobs per lane, MEL_J quads of four bins per job ------
-        // A job multiplies MEL_J consecutive quads of the power spectrum with its weights and
-        // writes the partial sum to its cell; a filter's output is the sum of its cells, and the
-        // outputs leave as coalesced rows.  (Filterbanks cut into more jobs per filter than
-        // there are cell rows share one cell per filter through LDS atomics, which one wavefront
-        // executes in program order, so that sum is deterministic too -- but slow.)
+        // A job multiplies MEL_J consecutive quads of the power spectrum with its weights; the
+        // jobs of a chain (consecutive slots of one lane) add up in a register and the last one
+        // writes the sum to the chain's cell.  A filter's output is the sum of its cells, and the
+        // outputs leave as coalesced rows.  (Filterbanks that would need more cell rows than
+        // there are share one cell per filter through LDS atomics, which one wavefront executes
+        // in program order, so that sum is deterministic too -- but slow.)
         if (a.mel_out && !(a.ablate & 1)) {
             const int2* jp = (MELW_LDS ? jobs_l : a.mel_jobs) + lane;
             const float4* wp = (MELW_LDS ? melw_l : a.melw) + lane;
-            const char* Xb = reinterpret_cast<const char*>(X);
-            if (n_jobs <= MEL_REG_JOBS) {
-                // all reads of MEL_BATCH jobs in flight at once (n_jobs >= 4 here means n_jobs == 4)
-#pragma unroll
-                for (int j = 0; j < MEL_REG_JOBS; j += MEL_BATCH) {
-                    if (j < n_jobs) {
-                        float4 w[MEL_BATCH][MEL_J], v[MEL_BATCH][MEL_J];
-#pragma unroll
-                        for (int u = 0; u < MEL_BATCH; ++u) {
-                            const float4* pp = reinterpret_cast<const float4*>(Xb + jobr[j + u].x);
-#pragma unroll
-                            for (int i = 0; i < MEL_J; ++i) {
-                                w[u][i] = wp[((j + u) * MEL_J + i) * 64];
-                                v[u][i] = pp[i];
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < MEL_BATCH; ++u) {
-                            float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll
-                            for (int i = 0; i < MEL_J; ++i) {
-                                acc0 = fmaf(w[u][i].x, v[u][i].x, acc0);
-                                acc1 = fmaf(w[u][i].y, v[u][i].y, acc1);
-                                acc0 = fmaf(w[u][i].z, v[u][i].z, acc0);
-                                acc1 = fmaf(w[u][i].w, v[u][i].w, acc1);
-                            }
-                            float* acc_p = reinterpret_cast<float*>(const_cast<char*>(Xb) + jobr[j + u].y);
-                            if (!a.mel_shared) *acc_p = acc0 + acc1;
-                            else __hip_atomic_fetch_add(acc_p, acc0 + acc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        }
-                    }
-                }
-            } else {
-            int2 job = jp[0];
-            for (int j = 0; j < n_jobs; ++j) {
-                const float4* pp = reinterpret_cast<const float4*>(Xb + job.x);
-                float* acc_p = reinterpret_cast<float*>(const_cast<char*>(Xb) + job.y);
-                float4 w[MEL_J], v[MEL_J];
-#pragma unroll
-                for (int i = 0; i < MEL_J; ++i) { w[i] = wp[(j * MEL_J + i) * 64]; v[i] = pp[i]; }
-                if (j + 1 < n_jobs) job = jp[(j + 1) * 64];
-                __builtin_amdgcn_sched_barrier(0);   // 2 * MEL_J + 1 reads in flight
+            char* Xb = reinterpret_cast<char*>(X);
+            auto job_sum = [&](const float4 (&w)[MEL_J], const float4 (&v)[MEL_J]) -> float {
                 float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
                 for (int i = 0; i < MEL_J; ++i) {
@@ -568,32 +573,57 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
                     acc0 = fmaf(w[i].z, v[i].z, acc0);
                     acc1 = fmaf(w[i].w, v[i].w, acc1);
                 }
-                if (!a.mel_shared) *acc_p = acc0 + acc1;
-                else __hip_atomic_fetch_add(acc_p, acc0 + acc1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-            }
-            float* mo = a.mel_out + row * a.n_mels;
-            const float* cells = X + MCELL_OFF + lane;
+                return acc0 + acc1;
+            };
+            auto put = [&](int cell_off, float v) {
+                float* c = reinterpret_cast<float*>(Xb + cell_off);
+                if (!a.mel_shared) *c = v;
+                else __hip_atomic_fetch_add(c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            };
+            float chain = 0.0f;
+            if (MELW_LDS && n_jobs <= MEL_REG_JOBS) {
+                // all reads of MEL_BATCH jobs in flight at once (n_jobs == MEL_REG_JOBS here)
+                const uint4 jq = reinterpret_cast<const uint4*>(jobs_l)[lane];
+                const uint32_t jobr[MEL_REG_JOBS] = {jq.x, jq.y, jq.z, jq.w};
 #pragma unroll
-            for (int p = 0; p < MAX_MEL_PASS; ++p) {
-                if (p < n_acc) {
-                    const int f = 64 * p + lane;
-                    // all reads of the group in flight at once; rows past the group's last are
-                    // re-reads of that last row and do not enter the sum
-                    const int R = a.mel_rows[p];
-                    float v[MEL_MAX_ROWS];
+                for (int j = 0; j < MEL_REG_JOBS; j += MEL_BATCH) {
+                    float4 w[MEL_BATCH][MEL_J], v[MEL_BATCH][MEL_J];
+                    uint32_t jr[MEL_BATCH];
 #pragma unroll
-                    for (int c = 0; c < MEL_MAX_ROWS; ++c) v[c] = cells[64 * min(c, R - 1)];
-                    float acc = v[0];
+                    for (int u = 0; u < MEL_BATCH; ++u) {
+                        jr[u] = jobr[j + u];
+                        const float4* pp = reinterpret_cast<const float4*>(Xb + (jr[u] & 0xffffu));
 #pragma unroll
-                    for (int c = 1; c < MEL_MAX_ROWS; ++c) acc += (c < R) ? v[c] : 0.0f;
-                    cells += 64 * R;
-                    if (f < a.n_mels) {
-                        mo[f] = acc;
-                        runmax = fmaxf(runmax, acc);
+                        for (int i = 0; i < MEL_J; ++i) {
+                            w[u][i] = wp[((j + u) * MEL_J + i) * 64];
+                            v[u][i] = pp[i];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < MEL_BATCH; ++u) {
+                        const float part = job_sum(w[u], v[u]);
+                        chain = (jr[u] & 0x10000u) ? chain + part : part;
+                        put((jr[u] >> 16) & ~3u, chain);
                     }
                 }
+            } else {
+                int2 job = jp[0];
+                for (int j = 0; j < n_jobs; ++j) {
+                    const float4* pp = reinterpret_cast<const float4*>(Xb + job.x);
+                    const int cell_off = job.y & ~3;
+                    const bool cont = job.y & 1;
+                    float4 w[MEL_J], v[MEL_J];
+#pragma unroll
+                    for (int i = 0; i < MEL_J; ++i) { w[i] = wp[(j * MEL_J + i) * 64]; v[i] = pp[i]; }
+                    if (j + 1 < n_jobs) job = jp[(j + 1) * 64];
+                    __builtin_amdgcn_sched_barrier(0);   // 2 * MEL_J + 1 reads in flight
+                    const float part = job_sum(w, v);
+                    chain = cont ? chain + part : part;
+                    put(cell_off, chain);
+                }
             }
+            collect_outputs(row);
         }
 
     }

@@ -303,33 +303,141 @@ void build_sparse_mel(const std::vector<float>& basis, int n_mels, int n_bins, i
 namespace {
 struct MelJob {
     int filt;    // filter
-    int seq;     // index among the filter's jobs
     int quad;    // first quad, in units of 4 floats of the padded layout
     int slack;   // the job may start up to this many quads earlier
-    int cell;    // (slot * 4 + group) * 16 + residue once placed, else -1
-    int shift;   // quads the job was moved down by
+};
+struct MelChain {
+    int filt, index;       // filter and which of its chains this is
+    int first, len;        // jobs[first .. first + len)
+};
+struct Placement {
+    std::vector<int> lane, slot0;   // per chain
+    std::vector<int> shift;         // per job
+    int conflicts = 0;
+    bool ok = false;
 };
 
-// Kuhn's matching of jobs to (slot, lane group, bank-group residue) cells.
-struct JobMatcher {
-    int n_slots;
-    std::vector<MelJob>* jobs;
-    std::vector<int> owner;  // per cell
-    bool try_assign(int i, std::vector<char>& seen) {
-        const MelJob& jb = (*jobs)[i];
-        for (int ds = 0; ds < n_slots; ++ds) {
-            const int s = (jb.seq + ds) % n_slots;   // a filter's jobs prefer different slots
-            for (int g = 0; g < 4; ++g)
-                for (int d = 0; d <= jb.slack && d <= jb.quad; ++d) {
-                    const int cell = (s * 4 + g) * 16 + (jb.quad - d) % 16;
-                    if (seen[cell]) continue;
-                    seen[cell] = 1;
-                    if (owner[cell] < 0 || try_assign(owner[cell], seen)) { owner[cell] = i; return true; }
-                }
+// Lanes of the four 16-lane groups a ds_read_b128 is serviced in, inverted.
+void lane_groups(int (&group_of)[64]) {
+    for (int g = 0; g < 4; ++g)
+        for (int j = 0; j < 16; ++j) group_of[kB128Groups[g][j]] = g;
+}
+
+// One greedy pass: chains in the given order, each to the lane (with room) where its jobs collide
+// with the fewest bank-group residues already taken in that lane's group, fullest lane first
+// among equals.
+Placement place_chains(const std::vector<MelJob>& jobs, const std::vector<MelChain>& chains,
+                       const std::vector<int>& order, int n_slots, uint32_t seed) {
+    int group_of[64];
+    lane_groups(group_of);
+    Placement pl;
+    pl.lane.assign(chains.size(), -1);
+    pl.slot0.assign(chains.size(), 0);
+    pl.shift.assign(jobs.size(), 0);
+    std::vector<int> fill(64, 0);
+    std::vector<char> used((size_t)4 * n_slots * 16, 0);
+    std::vector<int> best_shift, cur_shift;
+    for (int ci : order) {
+        const MelChain& c = chains[ci];
+        int best_lane = -1, best_cost = 1 << 30;
+        for (int l = 0; l < 64; ++l) {
+            if (fill[l] + c.len > n_slots) continue;
+            const int g = group_of[l];
+            int conf = 0;
+            cur_shift.assign(c.len, 0);
+            for (int i = 0; i < c.len; ++i) {
+                const MelJob& jb = jobs[c.first + i];
+                const int s = fill[l] + i;
+                int d_ok = -1;
+                for (int d = 0; d <= jb.slack && d <= jb.quad; ++d)
+                    if (!used[((size_t)g * n_slots + s) * 16 + (jb.quad - d) % 16]) { d_ok = d; break; }
+                if (d_ok < 0) { ++conf; d_ok = 0; }
+                cur_shift[i] = d_ok;
+            }
+            // seed != 0: equal candidates in a pseudo-random order
+            seed = seed * 1664525u + 1013904223u;
+            const int noise = seed ? (int)((seed >> 10) & 7) : g;
+            const int cost = conf * 1024 + (n_slots - fill[l]) * 8 + noise;
+            if (cost < best_cost) { best_cost = cost; best_lane = l; best_shift = cur_shift; }
         }
-        return false;
+        if (best_lane < 0) return pl;   // no room: not ok
+        const int g = group_of[best_lane];
+        pl.lane[ci] = best_lane;
+        pl.slot0[ci] = fill[best_lane];
+        for (int i = 0; i < c.len; ++i) {
+            const MelJob& jb = jobs[c.first + i];
+            pl.shift[c.first + i] = best_shift[i];
+            char& u = used[((size_t)g * n_slots + fill[best_lane] + i) * 16 + (jb.quad - best_shift[i]) % 16];
+            if (u) ++pl.conflicts;
+            u = 1;
+        }
+        fill[best_lane] += c.len;
     }
-};
+    pl.ok = true;
+    return pl;
+}
+
+// Bank-group collisions of a complete assignment (chains per lane, in slot order); fills in
+// slot0 and the per-job shifts it chose.
+int count_conflicts(const std::vector<MelJob>& jobs, const std::vector<MelChain>& chains,
+                    const std::vector<std::vector<int>>& lane_chains, int n_slots, Placement* pl) {
+    int group_of[64];
+    lane_groups(group_of);
+    std::vector<char> used((size_t)4 * n_slots * 16, 0);
+    int conflicts = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int g = group_of[l];
+        int s = 0;
+        for (int ci : lane_chains[l]) {
+            const MelChain& c = chains[ci];
+            if (pl) { pl->lane[ci] = l; pl->slot0[ci] = s; }
+            for (int i = 0; i < c.len; ++i, ++s) {
+                const MelJob& jb = jobs[c.first + i];
+                int d_ok = -1;
+                for (int d = 0; d <= jb.slack && d <= jb.quad; ++d)
+                    if (!used[((size_t)g * n_slots + s) * 16 + (jb.quad - d) % 16]) { d_ok = d; break; }
+                if (d_ok < 0) { ++conflicts; d_ok = 0; }
+                used[((size_t)g * n_slots + s) * 16 + (jb.quad - d_ok) % 16] = 1;
+                if (pl) pl->shift[c.first + i] = d_ok;
+            }
+        }
+    }
+    return conflicts;
+}
+
+// Local search from a greedy placement: swap equal-length chains between lanes, swap whole
+// lanes, rotate the chains of a lane; keep whatever does not add collisions.
+void improve_placement(const std::vector<MelJob>& jobs, const std::vector<MelChain>& chains, int n_slots,
+                       Placement& pl) {
+    std::vector<std::vector<int>> lanes(64);
+    std::vector<int> by_slot(chains.size());
+    std::iota(by_slot.begin(), by_slot.end(), 0);
+    std::stable_sort(by_slot.begin(), by_slot.end(), [&](int a, int b) { return pl.slot0[a] < pl.slot0[b]; });
+    for (int ci : by_slot) lanes[pl.lane[ci]].push_back(ci);
+    int cur = count_conflicts(jobs, chains, lanes, n_slots, nullptr);
+    uint32_t rng = 2463534242u;
+    auto next = [&](uint32_t n) { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return rng % n; };
+    for (int it = 0; it < 30000 && cur > 0; ++it) {
+        const int la = (int)next(64), lb = (int)next(64);
+        const int kind = (int)next(3);
+        auto trial = lanes;
+        if (kind == 0) {
+            if (la == lb || trial[la].empty() || trial[lb].empty()) continue;
+            const size_t ia = next((uint32_t)trial[la].size()), ib = next((uint32_t)trial[lb].size());
+            if (chains[trial[la][ia]].len != chains[trial[lb][ib]].len) continue;
+            std::swap(trial[la][ia], trial[lb][ib]);
+        } else if (kind == 1) {
+            if (la == lb) continue;
+            std::swap(trial[la], trial[lb]);
+        } else {
+            if (trial[la].size() < 2) continue;
+            std::rotate(trial[la].begin(), trial[la].begin() + 1, trial[la].end());
+        }
+        const int c = count_conflicts(jobs, chains, trial, n_slots, nullptr);
+        if (c <= cur) { cur = c; lanes.swap(trial); }
+    }
+    pl.conflicts = count_conflicts(jobs, chains, lanes, n_slots, &pl);
+}
 }  // namespace
 
 void build_mel_jobs(const std::vector<float>& basis, int n_mels, int n_bins, int quads, int row_bins,
@@ -337,53 +445,85 @@ void build_mel_jobs(const std::vector<float>& basis, int n_mels, int n_bins, int
     const int J = quads;
     const int pad_quads = (row_stride - row_bins) / 4;
     auto addr = [&](int bin) { return bin + (row_stride - row_bins) * (bin / row_bins); };
-    std::vector<int> first(n_mels, 0), last(n_mels, -1);
+    std::vector<int> first(n_mels, 0), last(n_mels, -1), job0(n_mels + 1, 0);
     std::vector<MelJob> jobs;
     for (int m = 0; m < n_mels; ++m) {
+        job0[m] = (int)jobs.size();
         int lo = -1, hi = -1;
         for (int k = 0; k < n_bins; ++k)
             if (basis[(size_t)m * n_bins + k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
         if (lo < 0) continue;
         first[m] = lo; last[m] = hi;
-        int seq = 0;
         for (int r = lo / row_bins; r <= hi / row_bins; ++r) {
             const int a = std::max(lo, r * row_bins), b = std::min(hi, (r + 1) * row_bins - 1);
             const int t0 = addr(a) / 4, nq = addr(b) / 4 - t0 + 1, nj = (nq + J - 1) / J;
             for (int i = 0; i < nj; ++i) {
                 const int slack = (i == nj - 1) ? std::min(J * nj - nq, pad_quads) : 0;
-                jobs.push_back(MelJob{m, seq++, t0 + J * i, slack, -1, 0});
+                jobs.push_back(MelJob{m, t0 + J * i, slack});
             }
         }
     }
-    // the kernel runs up to four jobs per lane as one batch: never fewer than four
-    const int n_slots = std::max(4, ((int)jobs.size() + 63) / 64);
-    JobMatcher mt{n_slots, &jobs, std::vector<int>((size_t)n_slots * 64, -1)};
-    std::vector<int> idx(jobs.size());
-    std::iota(idx.begin(), idx.end(), 0);
-    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return jobs[a].slack < jobs[b].slack; });
-    std::vector<int> unplaced;
-    for (int i : idx) {
-        std::vector<char> seen(mt.owner.size(), 0);
-        if (!mt.try_assign(i, seen)) unplaced.push_back(i);
+    job0[n_mels] = (int)jobs.size();
+    const int n_groups = (n_mels + 63) / 64;
+
+    // The kernel runs up to four jobs per lane as one batch: never fewer than four slots.
+    int n_slots = std::max(4, ((int)jobs.size() + 63) / 64);
+    std::vector<MelChain> chains;
+    Placement best;
+    for (;; ++n_slots) {
+        // a filter's jobs form chains of at most n_slots consecutive jobs, one lane each
+        chains.clear();
+        for (int m = 0; m < n_mels; ++m) {
+            const int n = job0[m + 1] - job0[m];
+            if (n == 0) continue;
+            const int nc = (n + n_slots - 1) / n_slots;
+            int at = job0[m];
+            for (int c = 0; c < nc; ++c) {
+                const int len = n / nc + (c < n % nc ? 1 : 0);
+                chains.push_back(MelChain{m, c, at, len});
+                at += len;
+            }
+        }
+        // longest chains first; a few deterministic reshuffles of the equal-length runs
+        std::vector<int> order(chains.size());
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return chains[a].len > chains[b].len; });
+        best = Placement();
+        uint32_t rng = 12345u;
+        for (int attempt = 0; attempt < 16; ++attempt) {
+            if (attempt > 0) {
+                for (size_t i = 0; i + 1 < order.size(); ++i) {
+                    rng = rng * 1664525u + 1013904223u;
+                    size_t hi = i;
+                    while (hi + 1 < order.size() && chains[order[hi + 1]].len == chains[order[i]].len) ++hi;
+                    const size_t j = i + (rng >> 8) % (hi - i + 1);
+                    std::swap(order[i], order[j]);
+                }
+            }
+            Placement pl = place_chains(jobs, chains, order, n_slots, attempt == 0 ? 0u : rng | 1u);
+            if (pl.ok && (!best.ok || pl.conflicts < best.conflicts)) best = pl;
+            if (best.ok && best.conflicts == 0) break;
+        }
+        if (best.ok) break;
     }
-    // lanes: within a (slot, group) the matched jobs take the group's lanes in residue order;
-    // jobs the matching could not place fill the remaining lanes (and may bank-conflict)
+    if (best.conflicts > 0) improve_placement(jobs, chains, n_slots, best);
+
     out.n_jobs = n_slots;
     out.quads = J;
     out.at.assign((size_t)n_slots * 64, 0);
     out.cell.assign((size_t)n_slots * 64, 0);
+    out.cont.assign((size_t)n_slots * 64, 0);
     out.w.assign((size_t)n_slots * J * 64 * 4, 0.0f);
     out.max_read = 0;
-    out.bank_conflicts = (int)unplaced.size();
-    // cell rows: a filter cut into n jobs needs n rows in its group of 64 filters
-    std::vector<int> n_of(n_mels, 0);
-    for (const MelJob& jb : jobs) n_of[jb.filt] = std::max(n_of[jb.filt], jb.seq + 1);
-    const int n_groups = (n_mels + 63) / 64;
+    out.bank_conflicts = best.conflicts;
+    // cell rows: one per chain of the filter with the most chains in each group of 64 filters
+    std::vector<int> n_chains(n_mels, 0);
+    for (const MelChain& c : chains) n_chains[c.filt] = std::max(n_chains[c.filt], c.index + 1);
     out.n_rows = 0;
     for (int p = 0; p < 4; ++p) {
         out.rows[p] = 0;
         if (p >= n_groups) continue;
-        for (int f = 64 * p; f < std::min(n_mels, 64 * p + 64); ++f) out.rows[p] = std::max(out.rows[p], n_of[f]);
+        for (int f = 64 * p; f < std::min(n_mels, 64 * p + 64); ++f) out.rows[p] = std::max(out.rows[p], n_chains[f]);
         out.rows[p] = std::max(out.rows[p], 1);
         out.n_rows += out.rows[p];
     }
@@ -395,38 +535,36 @@ void build_mel_jobs(const std::vector<float>& basis, int n_mels, int n_bins, int
     }
     std::vector<int> row0(5, 0);
     for (int p = 0; p < 4; ++p) row0[p + 1] = row0[p] + out.rows[p];
-    for (int s = 0; s < n_slots; ++s)
-        for (int l = 0; l < 64; ++l) out.cell[s * 64 + l] = out.n_rows * 64 + l;
-    std::vector<int> job_slot(jobs.size(), -1), job_lane(jobs.size(), -1);
-    size_t next_unplaced = 0;
-    for (int s = 0; s < n_slots; ++s)
-        for (int g = 0; g < 4; ++g) {
-            int j = 0;
-            for (int res = 0; res < 16; ++res) {
-                const int i = mt.owner[(s * 4 + g) * 16 + res];
-                if (i < 0) continue;
-                jobs[i].shift = ((jobs[i].quad - res) % 16 + 16) % 16;
-                job_slot[i] = s; job_lane[i] = kB128Groups[g][j++];
-            }
-            for (; j < 16 && next_unplaced < unplaced.size(); ++j) {
-                const int i = unplaced[next_unplaced++];
-                jobs[i].shift = 0;
-                job_slot[i] = s; job_lane[i] = kB128Groups[g][j];
-            }
+    // rows some filter of the group leaves unwritten must be cleared before every frame
+    out.zero_rows = 0;
+    for (int p = 0; p < n_groups; ++p)
+        for (int c = 0; c < out.rows[p]; ++c) {
+            bool hole = out.shared;
+            for (int f = 64 * p; f < std::min(n_mels, 64 * p + 64); ++f) hole = hole || n_chains[f] <= c;
+            if (hole) out.zero_rows |= 1u << (row0[p] + c);
         }
+    for (int s = 0; s < n_slots; ++s)
+        for (int l = 0; l < 64; ++l) out.cell[s * 64 + l] = out.n_rows * 64 + l;   // idle / mid-chain
+
     std::vector<char> done((size_t)n_mels * n_bins, 0);
-    for (size_t i = 0; i < jobs.size(); ++i) {      // in filter order, a filter's jobs in sequence
-        const MelJob& jb = jobs[i];
-        const int s = job_slot[i], l = job_lane[i];
-        const int at = 4 * (jb.quad - jb.shift);
-        out.at[s * 64 + l] = at;
-        out.cell[s * 64 + l] = (row0[jb.filt / 64] + (out.shared ? 0 : jb.seq)) * 64 + (jb.filt & 63);
-        out.max_read = std::max(out.max_read, at + 4 * J - 1);
-        for (int k = first[jb.filt]; k <= last[jb.filt]; ++k) {
-            const int rel = addr(k) - at;
-            if (rel < 0 || rel >= 4 * J || done[(size_t)jb.filt * n_bins + k]) continue;
-            done[(size_t)jb.filt * n_bins + k] = 1;
-            out.w[((size_t)(s * J + rel / 4) * 64 + l) * 4 + (rel & 3)] = basis[(size_t)jb.filt * n_bins + k];
+    for (size_t ci = 0; ci < chains.size(); ++ci) {      // in filter order, a filter's jobs in sequence
+        const MelChain& c = chains[ci];
+        const int l = best.lane[ci];
+        for (int i = 0; i < c.len; ++i) {
+            const MelJob& jb = jobs[c.first + i];
+            const int s = best.slot0[ci] + i;
+            const int at = 4 * (jb.quad - best.shift[c.first + i]);
+            out.at[s * 64 + l] = at;
+            out.cont[s * 64 + l] = i > 0;
+            if (i == c.len - 1)
+                out.cell[s * 64 + l] = (row0[c.filt / 64] + (out.shared ? 0 : c.index)) * 64 + (c.filt & 63);
+            out.max_read = std::max(out.max_read, at + 4 * J - 1);
+            for (int k = first[c.filt]; k <= last[c.filt]; ++k) {
+                const int rel = addr(k) - at;
+                if (rel < 0 || rel >= 4 * J || done[(size_t)c.filt * n_bins + k]) continue;
+                done[(size_t)c.filt * n_bins + k] = 1;
+                out.w[((size_t)(s * J + rel / 4) * 64 + l) * 4 + (rel & 3)] = basis[(size_t)c.filt * n_bins + k];
+            }
         }
     }
 }

@@ -51,30 +51,35 @@ void build_sparse_mel(const std::vector<float>& basis, int n_mels, int n_bins, i
 // The power spectrum lives in rows of row_bins bins, row r starting at float r * row_stride
 // (row_stride - row_bins floats of padding after each row).  Every filter's support is cut at
 // the row boundaries and then into jobs of `quads` consecutive 4-bin quads; each lane of the
-// wavefront runs n_jobs >= 4 jobs per frame.  Job j of lane l:
+// wavefront runs n_jobs >= 4 jobs per frame, one per slot.  Consecutive jobs of a filter form a
+// chain that sits in consecutive slots of one lane, so the lane adds them up in a register;
+// a filter with more jobs than slots has several chains.  Job j of lane l:
 //   at[j*64+l]    float index of the job's first quad (a multiple of 4) in the padded layout
-//   cell[j*64+l]  where the job's partial sum goes, in floats from the start of the cell area
+//   cont[j*64+l]  1 if the job continues the chain of slot j - 1 (add that slot's running sum)
+//   cell[j*64+l]  where the running sum goes after this job, in floats from the start of the
+//                 cell area: a real cell for the last job of a chain, else row n_rows, cell l
 //   w[((j*quads + i)*64 + l)*4 + c]   weight of bin c of quad i
-// Cell area: for each group p of 64 filters, rows[p] rows of 64 cells; filter f = 64 p + x owns
-// cell x of each of its group's rows.  If no filter is cut into more than max_rows jobs in total
-// over the groups (sum of rows[p] <= max_rows, each rows[p] <= max_rows_per_group), every job
-// has a cell of its own and the
-// filter's output is the sum of its cells (cells no job writes must read as zero); otherwise
-// `shared` is set, rows[p] = 1 and the jobs of a filter add into one cell.  Idle jobs (all
-// weights zero) write to row sum(rows), cell l.
-// Jobs are dealt to (job slot, lane) so that the 16 lanes a ds_read_b128 services together read
-// from distinct LDS bank groups wherever the filter geometry allows it.
+// Cell area: for each group p of 64 filters, rows[p] rows of 64 cells; chain c of filter
+// f = 64 p + x owns cell x of row c of its group, and the filter's output is the sum over its
+// group's rows (rows with unwritten cells -- bits of zero_rows -- must be cleared each frame).
+// If that takes more rows than allowed (sum of rows[p] <= max_rows, rows[p] <=
+// max_rows_per_group) `shared` is set instead: rows[p] = 1 and all chains of a filter add
+// into its one cell.
+// Chains are dealt to lanes so that the 16 lanes a ds_read_b128 services together read from
+// distinct LDS bank groups wherever the filter geometry allows it.
 struct MelJobs {
     int n_jobs = 0;
     int quads = 0;
     std::vector<int32_t> at;
     std::vector<int32_t> cell;
+    std::vector<int32_t> cont;
     std::vector<float> w;
     int rows[4] = {0, 0, 0, 0};
     int n_rows = 0;         // sum of rows[]
+    uint32_t zero_rows = 0;
     bool shared = false;
     int max_read = 0;       // largest float index any job reads
-    int bank_conflicts = 0; // jobs that could not be given a conflict-free (slot, lane)
+    int bank_conflicts = 0; // jobs that share a bank group with another job of their read group
 };
 void build_mel_jobs(const std::vector<float>& basis, int n_mels, int n_bins, int quads, int row_bins,
                     int row_stride, int max_rows, int max_rows_per_group, MelJobs& out);

@@ -517,7 +517,7 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
     }
     std::vector<int2> jobs;
     if (p->fast2048) {
-        mfcc_host::build_mel_jobs(basis, r.c.n_mels, r.n_bins, k2048::MEL_J, 128, k2048::P_ROW,
+        mfcc_host::build_mel_jobs(basis, r.c.n_mels, r.n_bins, k2048::MEL_J, k2048::P_ROW_BINS, k2048::P_ROW,
                                   k2048::MCELL_ROWS - 1, k2048::MEL_MAX_ROWS, p->mj);
         if (p->mj.max_read >= k2048::P_END) {
             delete p;
@@ -525,7 +525,7 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         }
         jobs.resize(p->mj.at.size());
         for (size_t i = 0; i < jobs.size(); ++i)
-            jobs[i] = make_int2(4 * p->mj.at[i], 4 * (k2048::MCELL_OFF + p->mj.cell[i]));
+            jobs[i] = make_int2(4 * p->mj.at[i], 4 * (k2048::MCELL_OFF + p->mj.cell[i]) | (p->mj.cont[i] ? 1 : 0));
     }
     std::vector<float> dfrag;
     if (!p->fast2048) {
@@ -667,6 +667,7 @@ static int launch_front(const mfcc_plan* plan, const float* d_pcm, const int64_t
     fa.mel_out = mel_out; fa.spec_out = spec_out; fa.gmax = gmax;
     fa.n_jobs = plan->mj.n_jobs; fa.n_mels = plan->r.c.n_mels;
     fa.mel_shared = plan->mj.shared ? 1 : 0;
+    fa.mel_zero_rows = plan->mj.zero_rows;
     for (int i = 0; i < 4; ++i) fa.mel_rows[i] = plan->mj.rows[i];
     fa.hop = plan->r.c.hop_length;
     fa.pad = plan->r.c.center ? plan->r.c.n_fft / 2 : 0;
