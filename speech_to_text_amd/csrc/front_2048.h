@@ -29,10 +29,17 @@ namespace k2048 {
 constexpr int NFFT = 2048;
 constexpr int NBIN = 1025;
 constexpr int TILE_FRAMES = 16;
-// Exchange column: 64 complex, 2 complex of padding after every 16, stride 72: the
-// ds_write_b64 of step 1 and the ds_read_b128 of step 2 are both bank-conflict free.
-constexpr int COL_STRIDE = 72;
-constexpr int XCH_FLOATS = (15 * COL_STRIDE + 70) * 2;   // 2300 floats per wavefront
+// Exchange: 16 columns of 64 complex, no padding (8 KB per wavefront, so that 16 wavefronts and
+// the tables fit the CU's 160 KB).  Step 2 reads a column two complex (16 bytes) at a time; to
+// keep those ds_read_b128 bank-conflict free the pairs of a column are stored swizzled: pair
+// 8 q + p (q = 0..3, p = 0..7) of column k2 sits at pair slot 8 q + (p ^ g), g = 2 (k2 & 3) +
+// (q >> 1).  The 16 lanes the hardware services together then hit 16 different bank groups,
+// and the ds_write_b64 of step 1 stay a permutation within the column (conflict free).
+constexpr int COL_STRIDE = 64;
+constexpr int XCH_FLOATS = 16 * COL_STRIDE * 2;   // 2048 floats per wavefront
+__host__ __device__ constexpr int xch_slot(int k2, int c) {   // complex index of element c of column k2
+    return k2 * COL_STRIDE + 16 * (c >> 4) + 2 * (((c >> 1) & 7) ^ (2 * (k2 & 3) + (c >> 5))) + (c & 1);
+}
 // After step 2 the same region holds, per wavefront:
 //   the power spectrum in rows of 64 bins, 80 floats apart: bin k at k + 16 (k >> 6).  With the
 //   16 floats of padding the 64 lanes of one power-spectrum store (bins 32 kb + k2c + 128 ka)
@@ -48,7 +55,7 @@ constexpr int P_END = 16 * P_ROW + 16;            // bin 1024 sits at 1280; read
 constexpr int SPECIAL_OFF = P_END;                // float offset of the column-0 scratch
 constexpr int SPECIAL_ROW = 24;                   // complex per kb row of that scratch
 constexpr int MCELL_OFF = SPECIAL_OFF + 4 * SPECIAL_ROW * 2;
-constexpr int MCELL_ROWS = (XCH_FLOATS - MCELL_OFF) / 64;   // 12, one of them for idle jobs
+constexpr int MCELL_ROWS = (XCH_FLOATS - MCELL_OFF) / 64;   // 8, one of them for idle jobs
 static_assert(MCELL_ROWS >= 5, "per-wavefront LDS region too small");
 constexpr int MEL_J = 3;                          // quads (of 4 bins) per mel job
 constexpr int MEL_REG_JOBS = 4;                   // jobs per lane that are kept in registers
@@ -282,9 +289,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     const float sgn2 = (q == 1 || q == 2) ? -1.0f : 1.0f;
     const bool lane3 = (q == 3);
     // exchange addressing (complex index c of column k2 lives at k2 * 72 + c + 2 * (c >> 4))
-    const int xw_off = lane + 2 * (lane >> 4);                  // step-1 write, + k2 * COL_STRIDE
-    const int y_off = lane + 4 * (lane >> 5);                   // column 0 as 128 reals
-    const int xr_off = k2c * COL_STRIDE + 18 * q;               // step-2 read (complex index)
+    // step-1 write of element `lane` of column k2: k2 * COL_STRIDE + xw[k2 & 3] (complex index)
+    const int xw[4] = {xch_slot(0, lane), xch_slot(1, lane) - COL_STRIDE, xch_slot(2, lane) - 2 * COL_STRIDE,
+                       xch_slot(3, lane) - 3 * COL_STRIDE};
+    // column 0 as 128 reals y[n] = component n & 1 of complex n >> 1: y[lane] and y[64 + lane]
+    const int y0_off = 2 * xch_slot(0, lane >> 1) + (lane & 1);
+    const int y1_off = 2 * xch_slot(0, 32 + (lane >> 1)) + (lane & 1);
+    // step-2 read of pairs 8 q + j, j = 0..7, of column k2c: float index xr_base ^ (4 j)
+    const int xr_base = 2 * (k2c * COL_STRIDE + 16 * q) + 4 * (2 * (k2c & 3) + (q >> 1));
     // power spectrum addressing: ka < 8 -> bin 128 ka + 32 kb + k2c; ka >= 8 -> its mirror image
     // bin 128 (15 - ka) + 128 - 32 kb - k2c (k2c > 0 there); 128 bins = 2 rows = 2 P_ROW floats
     const int pb0 = p_index(32 * kb + k2c);
@@ -448,12 +460,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             __builtin_amdgcn_sched_barrier(0);   // twiddle reads overlap the conjugate split
             float ar[16], ai[16];
             fc::rdft32_split(zr, zi, ar, ai);
-            X[y_off] = ar[0];                    // y[n1]      = sum over even n2
-            X[72 + y_off] = ai[0];               // y[64 + n1] = sum over odd n2
+            X[y0_off] = ar[0];                   // y[n1]      = sum over even n2
+            X[y1_off] = ai[0];                   // y[64 + n1] = sum over odd n2
 #pragma unroll
             for (int k2 = 1; k2 < 16; ++k2) {
                 fc::cmul(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
-                X2[k2 * COL_STRIDE + xw_off] = make_float2(ar[k2], ai[k2]);
+                X2[k2 * COL_STRIDE + xw[k2 & 3]] = make_float2(ar[k2], ai[k2]);
             }
         }
 
@@ -461,10 +473,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         float dr[16], di[16];
         {
             float2 w6[16];
-            const float4* src = reinterpret_cast<const float4*>(X2 + xr_off);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float4 v = src[j];
+                const float4 v = *reinterpret_cast<const float4*>(X + (xr_base ^ (4 * j)));
                 dr[2 * j] = v.x; di[2 * j] = v.y; dr[2 * j + 1] = v.z; di[2 * j + 1] = v.w;
             }
             if (W64_REGS) {

@@ -332,6 +332,8 @@ const FrontVariant kFrontVariants[] = {
     FRONT_VARIANT(12, IN_LDS, IN_LDS, true, true, 0, 0),    // 7: step-2 twiddles in registers
     FRONT_VARIANT(12, IN_REGS, IN_LDS, false, true, 0, 0),  // 8: window in registers
     FRONT_VARIANT(12, IN_REGS, IN_LDS, true, true, 0, 0),   // 9: both
+    FRONT_VARIANT(16, IN_LDS, IN_LDS, false, true, 0, 0),   // 10: 16 wavefronts, any hop
+    FRONT_VARIANT(16, IN_LDS, IN_LDS, false, false, 0, 0),  // 11: same, mel weights streamed
 };
 // power != 2: same structure as variants 0 (mel weights streamed) and 1 (mel weights in LDS).
 const FrontVariant kFrontGeneralPower[] = {
@@ -352,7 +354,7 @@ int select_variant(mfcc_plan* p) {
     };
     // default: reuse samples in registers when the hop allows it, mel weights in LDS when they fit
     int v = -1;
-    for (int cand : {2, 6, 1, 0})
+    for (int cand : {10, 2, 6, 1, 11, 0})
         if (usable(cand)) { v = cand; break; }
     if (const char* e = std::getenv("MFCC_HIP_VARIANT")) {
         const int w = std::atoi(e);
