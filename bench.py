@@ -62,47 +62,78 @@ def make_batch(hours: float, seed: int, device, lo_s=2.0, hi_s=35.0):
     return pcm, so
 
 
-def cpu_baseline(pcm, so, fo, gpu_out, sample_hours=0.5):
+def cpu_baseline(pcm, so, fo, gpu_out, target_seconds=30.0):
     """Times the CPU oracle (restatement of librosa 0.10.1; librosa is not installed) on a bounded
-    sample of the same utterances, one core, and checks the GPU result against it."""
+    sample of the same utterances and checks the GPU result against it.  Two figures, both from
+    oracle/cpu_bench.py in a child process: one process on one thread (the reported value) and a
+    worker pool shaped like the reference's mp.Pool(...).imap_unordered."""
+    import subprocess
+    import tempfile
     from oracle import mfcc_ref as R
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:  # pragma: no cover
-        threadpool_limits = None
-    n = 0
-    while n < len(so) - 1 and so[n + 1] < sample_hours * 3600 * SR:
+
+    # parity spot check + a rate estimate, in process
+    ncheck = min(8, len(so) - 1)
+    host = pcm[: int(so[ncheck])].cpu().numpy()
+    t0 = time.perf_counter()
+    feats = [R.process_audio_features(host[int(so[i]): int(so[i + 1])]) for i in range(ncheck)]
+    est_rate = (float(so[ncheck]) / SR / 3600.0) / max(time.perf_counter() - t0, 1e-6)
+    got = gpu_out[: int(fo[ncheck])].cpu().numpy()
+    worst = max(float(np.abs(got[int(fo[i]): int(fo[i + 1])] - f).max()) for i, f in enumerate(feats))
+
+    # sample: as many leading utterances as about target_seconds of one core
+    want_hours = est_rate * target_seconds
+    n = 1
+    while n < len(so) - 1 and so[n + 1] / SR / 3600.0 <= want_hours:
         n += 1
-    n = max(n, 1)
-    host = pcm[: int(so[n])].cpu().numpy()
-    utts = [host[int(so[i]): int(so[i + 1])] for i in range(n)]
-    ctx = threadpool_limits(limits=1) if threadpool_limits else None
-    if ctx is not None:
-        ctx.__enter__()
-    try:
-        R.process_audio_features(utts[0])  # warm caches / imports
-        t0 = time.perf_counter()
-        feats = [R.process_audio_features(u) for u in utts]
-        dt = time.perf_counter() - t0
-    finally:
-        if ctx is not None:
-            ctx.__exit__(None, None, None)
     hours = float(so[n]) / SR / 3600.0
-    worst = 0.0
-    got = gpu_out[: int(fo[n])].cpu().numpy()
-    for i, f in enumerate(feats):
-        worst = max(worst, float(np.abs(got[int(fo[i]): int(fo[i + 1])] - f).max()))
+    procs = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16)) - 1)
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "pcm.npy"), pcm[: int(so[n])].cpu().numpy())
+        np.save(os.path.join(td, "so.npy"), so[: n + 1])
+        env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+        for key, p, reps in (("single", 1, 1), ("pool", procs, max(1, procs // 2))):
+            r = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", os.path.join(td, "pcm.npy"),
+                                os.path.join(td, "so.npy"), str(n), str(p), str(reps)],
+                               cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                raise RuntimeError("oracle.cpu_bench failed: " + r.stderr[-2000:])
+            out[key] = json.loads(r.stdout.strip().splitlines()[-1])
+    single, pool = out["single"], out["pool"]
     return {
-        "value": hours / dt,
+        "value": single["hours"] / single["seconds"],
         "unit": "audio-hours/s",
         "cores": 1,
         "kind": "port",
         "sample": f"first {n} utterances ({hours:.3f} audio-hours) of the same batch, "
-                  f"numpy/scipy restatement of librosa 0.10.1 (librosa not installed), 1 thread",
-        "seconds": dt,
+                  f"numpy/scipy restatement of librosa 0.10.1 (librosa not installed), 1 process, 1 thread",
+        "seconds": single["seconds"],
+        "pool": {"value": pool["hours"] / pool["seconds"], "procs": pool["procs"], "seconds": pool["seconds"],
+                 "sample": f"the same {n} utterances x{max(1, procs // 2)}, mp.Pool({pool['procs']}).imap_unordered "
+                           f"as /root/reference/src/preprocess.py:156-160, 1 thread per worker"},
         "max_abs_diff_vs_gpu_db": worst,
         "host_cpus": os.cpu_count(),
     }
+
+
+def pcie_inclusive(plan, pcm, d_so, d_fo, total_frames, out, ws, total_samples):
+    """Audio-hours/s when the PCM starts in pinned host memory (float32 upload + compute, one
+    stream, no overlap): reported beside the device-resident value, never instead of it."""
+    host = torch.empty(pcm.shape, dtype=pcm.dtype, pin_memory=True)
+    host.copy_(pcm)
+    stage = torch.empty_like(pcm)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        stage.copy_(host, non_blocking=True)
+        plan.execute(stage, d_so, d_fo, total_frames, out=out, workspace=ws)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = min(times)
+    return {"value": total_samples / SR / 3600.0 / dt, "unit": "audio-hours/s", "ms": dt * 1e3,
+            "h2d_GBps": 4.0 * total_samples / dt / 1e9,
+            "note": "float32 PCM from pinned host memory, copy then compute on one stream"}
 
 
 def main():
@@ -245,6 +276,8 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pcm, so, fo, out)
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
+            plan.set_profiling(False)
+            line["pcie_inclusive"] = pcie_inclusive(plan, pcm, d_so, d_fo, total_frames, out, ws, total_samples)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
