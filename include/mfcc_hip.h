@@ -135,6 +135,16 @@ int mfcc_execute(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sam
                  int64_t total_frames, float* d_out, float* d_melspec_out, void* d_workspace,
                  size_t workspace_bytes, void* stream);
 
+/* Same as mfcc_execute with the audio as int16 PCM: sample value = d_pcm16[i] / 32768, exactly
+ * the float32 waveform torchaudio decodes a LibriSpeech FLAC into
+ * (/root/reference/src/preprocess.py:75 builds the dataset, :132-134 passes its float waveform
+ * on), so results are bit-identical to mfcc_execute on that waveform while the upload and the
+ * HBM reads are half the size. */
+int mfcc_execute_pcm16(const mfcc_plan* plan, const int16_t* d_pcm16, const int64_t* d_sample_offsets,
+                       const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
+                       int64_t total_frames, float* d_out, float* d_melspec_out, void* d_workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* |STFT|^power only: d_spec_out is (total_frames, 1 + n_fft/2) float32 row-major, i.e.
  * np.abs(librosa.stft(y))**power transposed (/root/reference/src/preprocess.py:111-113). */
 int mfcc_execute_spectrogram(const mfcc_plan* plan, const float* d_pcm,

@@ -84,6 +84,9 @@ SYMBOLS = {
     "mfcc_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_size_t, C.c_void_p]),
+    "mfcc_execute_pcm16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
     "mfcc_execute_spectrogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                            C.c_size_t, C.c_void_p]),

@@ -105,7 +105,7 @@ struct MelPass {
 };
 
 struct FrontArgs {
-    const float* pcm;
+    const void* pcm;         // float32 samples, or int16 PCM (value / 32768) when pcm16 is set
     const Tile* tiles;
     const WsHeader* hdr;
     const float* window;     // 2048
@@ -128,6 +128,7 @@ struct FrontArgs {
     int32_t pad;             // n_fft/2 if center else 0
     int32_t reflect;
     int32_t pw_mode;         // 0: power 2, 1: power 1, 2: general
+    int32_t pcm16;           // pcm holds int16 samples
     int32_t ablate;          // development only: bit 0 skips the mel stage
     float half_power;        // power / 2
 };
@@ -201,16 +202,25 @@ __device__ __forceinline__ void flush_max(float runmax, int grp, uint32_t* gmax,
 
 // Edge frames (those that overlap the zero / reflect padding) are rare: stage them through the
 // wavefront's LDS region with a rolled loop so the hot path stays small.
-__device__ __noinline__ void stage_edge_frame(float* X, const float* p, int start, int T, int reflect,
-                                              int lane) {
+// One sample as float32: int16 PCM maps to value / 32768 (exact), the way torchaudio decodes
+// LibriSpeech FLAC for /root/reference/src/preprocess.py:75.
+constexpr float PCM16_SCALE = 1.0f / 32768.0f;
+__device__ __forceinline__ float load_sample(const void* base, int64_t idx, bool pcm16) {
+    return pcm16 ? PCM16_SCALE * (float)static_cast<const int16_t*>(base)[idx]
+                 : static_cast<const float*>(base)[idx];
+}
+
+// `p`: first sample of the utterance.
+__device__ __noinline__ void stage_edge_frame(float* X, const void* pcm, int64_t soff, bool pcm16, int start,
+                                              int T, int reflect, int lane) {
 #pragma unroll 1
     for (int n2 = 0; n2 < 32; ++n2) {
         const int idx = start + lane + 64 * n2;
         float v = 0.0f;
         if (reflect) {
-            if (T > 0) v = p[reflect_index(idx, T)];
+            if (T > 0) v = load_sample(pcm, soff + reflect_index(idx, T), pcm16);
         } else if (idx >= 0 && idx < T) {
-            v = p[idx];
+            v = load_sample(pcm, soff + idx, pcm16);
         }
         X[lane + 64 * n2] = v;
     }
@@ -225,7 +235,8 @@ __device__ __noinline__ void stage_edge_frame(float* X, const float* p, int star
 // HOPR      0, or hop_length / 64 when that is an integer: samples shared with the previous frame
 //           stay in registers and only the new rows are loaded, one frame ahead
 // PW        0: |X|^2; 1: run-time power
-template <int WAVES, int WIN, int TW1, bool W64_REGS, bool MELW_LDS, int HOPR, int PW>
+// PCM16     the input is int16 PCM (HOPR = 0 only)
+template <int WAVES, int WIN, int TW1, bool W64_REGS, bool MELW_LDS, int HOPR, int PW, bool PCM16 = false>
 __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) {
     using namespace k2048;
     constexpr int THREADS = WAVES * 64;
@@ -406,16 +417,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         float r[32];
         {
             float* src = HOPR > 0 ? raw : r;
-            const float* pp = a.pcm + tc.soff + (t * a.hop - a.pad) + lane;
+            const int64_t s0 = tc.soff + (t * a.hop - a.pad) + lane;
+            const float* pp = static_cast<const float*>(a.pcm) + s0;
+            const int16_t* pp16 = static_cast<const int16_t*>(a.pcm) + s0;
             if (!interior) {
                 // edge frames (overlapping the padding) come through LDS
-                stage_edge_frame(X, a.pcm + tc.soff, t * a.hop - a.pad, tc.T, a.reflect, lane);
+                stage_edge_frame(X, a.pcm, tc.soff, PCM16, t * a.hop - a.pad, tc.T, a.reflect, lane);
 #pragma unroll
                 for (int n2 = 0; n2 < 32; ++n2) src[n2] = X[lane + 64 * n2];
                 // leave nothing of the staged samples behind: the padding of the power-spectrum
                 // rows is read (with zero weights) by the mel stage and must stay finite
 #pragma unroll 1
                 for (int i = lane; i < XCH_FLOATS; i += 64) X[i] = 0.0f;
+            } else if (PCM16) {
+                int16_t h[32];
+#pragma unroll
+                for (int n2 = 0; n2 < 32; ++n2) h[n2] = pp16[64 * n2];
+#pragma unroll
+                for (int n2 = 0; n2 < 32; ++n2) src[n2] = PCM16_SCALE * (float)h[n2];
             } else if (HOPR == 0 || !raw_ok) {
 #pragma unroll
                 for (int n2 = 0; n2 < 32; ++n2) src[n2] = pp[64 * n2];

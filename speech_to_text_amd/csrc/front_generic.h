@@ -20,7 +20,7 @@
 #include "front_2048.h"
 
 struct GenArgs {
-    const float* pcm;
+    const void* pcm;           // float32 samples, or int16 PCM (value / 32768) when pcm16 is set
     const Tile* tiles;
     const WsHeader* hdr;
     const float* window;       // n_fft
@@ -44,6 +44,7 @@ struct GenArgs {
     int32_t pad;
     int32_t reflect;
     int32_t pw_mode;
+    int32_t pcm16;
     float half_power;
 };
 
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const GenArgs a) {
         __syncthreads();   // previous tile's mel stage is done with P, its DFT with A
 
         // ---- stage: pad + frame + window ------------------------------------------------------
-        const float* p = a.pcm + ti.soff;
+        const bool pcm16 = a.pcm16 != 0;
         for (int fi = 0; fi < 4; ++fi) {
             const int f = 4 * wave + fi;
             float* rowp = A + f * a.lda;
@@ -99,9 +100,9 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const GenArgs a) {
                 if (f < nvalid && n < a.n_fft) {
                     const int idx = start + n;
                     if (a.reflect) {
-                        if (ti.T > 0) v = p[reflect_index(idx, ti.T)];
+                        if (ti.T > 0) v = load_sample(a.pcm, ti.soff + reflect_index(idx, ti.T), pcm16);
                     } else if (idx >= 0 && idx < ti.T) {
-                        v = p[idx];
+                        v = load_sample(a.pcm, ti.soff + idx, pcm16);
                     }
                     v *= a.window[n];
                 }

@@ -272,6 +272,7 @@ WsLayout ws_layout(int64_t total_frames, int32_t n_utts, int n_mels, bool need_m
 // ------------------------------------------------------------------------------------------
 struct FrontVariant {
     void (*fn)(const FrontArgs);
+    void (*fn16)(const FrontArgs);   // int16 PCM input; nullptr where the variant has no such build
     int waves;
     int win, tw1;            // k2048::TableHome
     bool w64_regs, melw_lds;
@@ -316,14 +317,17 @@ namespace {
 // Front-end kernel variants: wavefronts per workgroup (one workgroup per CU; LDS-limited) and
 // where the per-lane constant tables live.  MFCC_HIP_VARIANT selects one for experiments.
 #define FRONT_VARIANT(W, WIN, TW1, W64R, MELW, HOPR, PW) \
-    {k_melspec_2048<W, WIN, TW1, W64R, MELW, HOPR, PW>, W, WIN, TW1, W64R, MELW, HOPR}
+    {k_melspec_2048<W, WIN, TW1, W64R, MELW, HOPR, PW>, nullptr, W, WIN, TW1, W64R, MELW, HOPR}
+#define FRONT_VARIANT16(W, WIN, TW1, W64R, MELW, PW)                                                   \
+    {k_melspec_2048<W, WIN, TW1, W64R, MELW, 0, PW>, k_melspec_2048<W, WIN, TW1, W64R, MELW, 0, PW, true>, \
+     W, WIN, TW1, W64R, MELW, 0}
 using k2048::IN_GLOBAL;
 using k2048::IN_LDS;
 using k2048::IN_REGS;
 // hopr = 0 variants take any hop_length; hopr = 8 variants need hop_length = 512.
 const FrontVariant kFrontVariants[] = {
-    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, false, 0, 0),  // 0: fallback, mel weights streamed
-    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, true, 0, 0),   // 1: any hop
+    FRONT_VARIANT16(12, IN_LDS, IN_LDS, false, false, 0),   // 0: fallback, mel weights streamed
+    FRONT_VARIANT16(12, IN_LDS, IN_LDS, false, true, 0),    // 1: any hop
     FRONT_VARIANT(12, IN_LDS, IN_LDS, false, true, 8, 0),   // 2: hop 512, samples reused in registers
     FRONT_VARIANT(12, IN_REGS, IN_LDS, false, true, 8, 0),  // 3
     FRONT_VARIANT(8, IN_REGS, IN_LDS, true, true, 8, 0),    // 4
@@ -332,13 +336,13 @@ const FrontVariant kFrontVariants[] = {
     FRONT_VARIANT(12, IN_LDS, IN_LDS, true, true, 0, 0),    // 7: step-2 twiddles in registers
     FRONT_VARIANT(12, IN_REGS, IN_LDS, false, true, 0, 0),  // 8: window in registers
     FRONT_VARIANT(12, IN_REGS, IN_LDS, true, true, 0, 0),   // 9: both
-    FRONT_VARIANT(16, IN_LDS, IN_LDS, false, true, 0, 0),   // 10: 16 wavefronts, any hop
-    FRONT_VARIANT(16, IN_LDS, IN_LDS, false, false, 0, 0),  // 11: same, mel weights streamed
+    FRONT_VARIANT16(16, IN_LDS, IN_LDS, false, true, 0),    // 10: 16 wavefronts, any hop
+    FRONT_VARIANT16(16, IN_LDS, IN_LDS, false, false, 0),   // 11: same, mel weights streamed
 };
 // power != 2: same structure as variants 0 (mel weights streamed) and 1 (mel weights in LDS).
 const FrontVariant kFrontGeneralPower[] = {
-    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, false, 0, 1),
-    FRONT_VARIANT(12, IN_LDS, IN_LDS, false, true, 0, 1),
+    FRONT_VARIANT16(12, IN_LDS, IN_LDS, false, false, 1),
+    FRONT_VARIANT16(12, IN_LDS, IN_LDS, false, true, 1),
 };
 constexpr int kNumFrontVariants = sizeof(kFrontVariants) / sizeof(kFrontVariants[0]);
 
@@ -367,10 +371,12 @@ int select_variant(mfcc_plan* p) {
     p->variant = v;
     p->front_lds_bytes = k2048::lds_bytes(p->front.waves, p->front.win, p->front.tw1, p->front.w64_regs,
                                          p->front.melw_lds ? melw_floats : 0);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(p->front.fn),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)p->front_lds_bytes);
-    if (e2 != hipSuccess) return fail(MFCC_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e2));
+    for (auto fn : {p->front.fn, p->front.fn16}) {
+        if (!fn) continue;
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->front_lds_bytes);
+        if (e2 != hipSuccess) return fail(MFCC_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e2));
+    }
     return MFCC_OK;
 }
 
@@ -621,7 +627,7 @@ size_t mfcc_workspace_bytes(const mfcc_plan* plan, int64_t total_frames, int32_t
     return ws_layout(total_frames, n_utts, plan->r.c.n_mels, true).total;
 }
 
-static int launch_front(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sample_offsets,
+static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, const int64_t* d_sample_offsets,
                         const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
                         int64_t total_frames, float* mel_out, float* spec_out, char* ws,
                         const WsLayout& L, hipStream_t st) {
@@ -638,7 +644,7 @@ static int launch_front(const mfcc_plan* plan, const float* d_pcm, const int64_t
 
     if (!plan->fast2048) {
         GenArgs ga;
-        ga.pcm = d_pcm; ga.tiles = tiles; ga.hdr = hdr;
+        ga.pcm = d_pcm; ga.pcm16 = pcm16 ? 1 : 0; ga.tiles = tiles; ga.hdr = hdr;
         ga.window = plan->d_window; ga.dfrag = plan->d_dfrag;
         ga.melw = plan->d_melw; ga.mel_start = plan->d_mel_start; ga.mel_filt = plan->d_mel_filt;
         ga.mel_pass = plan->d_mel_pass;
@@ -663,7 +669,7 @@ static int launch_front(const mfcc_plan* plan, const float* d_pcm, const int64_t
         return MFCC_OK;
     }
     FrontArgs fa;
-    fa.pcm = d_pcm; fa.tiles = tiles; fa.hdr = hdr;
+    fa.pcm = d_pcm; fa.pcm16 = pcm16 ? 1 : 0; fa.tiles = tiles; fa.hdr = hdr;
     fa.window = plan->d_window; fa.tw1 = plan->d_tw1; fa.w64 = plan->d_w64; fa.tw128 = plan->d_tw128;
     fa.melw = plan->d_melw; fa.mel_jobs = plan->d_mel_jobs;
     fa.mel_out = mel_out; fa.spec_out = spec_out; fa.gmax = gmax;
@@ -681,7 +687,9 @@ static int launch_front(const mfcc_plan* plan, const float* d_pcm, const int64_t
     const int64_t wg_needed = (L.ub_tiles * TILE_FRAMES + fv.waves - 1) / fv.waves;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(wg_needed, plan->n_cu));
     if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
-    hipLaunchKernelGGL(fv.fn, dim3(grid), dim3(fv.waves * 64), plan->front_lds_bytes, st, fa);
+    if (pcm16 && !fv.fn16)
+        return fail(MFCC_E_UNSUPPORTED, "this kernel variant has no int16 build (unset MFCC_HIP_VARIANT)");
+    hipLaunchKernelGGL(pcm16 ? fv.fn16 : fv.fn, dim3(grid), dim3(fv.waves * 64), plan->front_lds_bytes, st, fa);
     if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[1], st));
     (void)total_frames;
     HIP_TRY(hipGetLastError());
@@ -700,10 +708,10 @@ static int check_batch(const mfcc_plan* plan, const void* d_pcm, const void* so,
     return MFCC_OK;
 }
 
-int mfcc_execute(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sample_offsets,
-                 const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
-                 int64_t total_frames, float* d_out, float* d_melspec_out, void* d_workspace,
-                 size_t workspace_bytes, void* stream) {
+static int execute_impl(const mfcc_plan* plan, const void* d_pcm, bool pcm16, const int64_t* d_sample_offsets,
+                        const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
+                        int64_t total_frames, float* d_out, float* d_melspec_out, void* d_workspace,
+                        size_t workspace_bytes, void* stream) {
     int rc = check_batch(plan, d_pcm, d_sample_offsets, d_frame_offsets, n_utts, total_frames);
     if (rc != MFCC_OK) return rc;
     if (n_utts == 0 || total_frames == 0) return MFCC_OK;
@@ -718,7 +726,7 @@ int mfcc_execute(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sam
     char* ws = static_cast<char*>(d_workspace);
     float* mel = need_mel ? reinterpret_cast<float*>(ws + L.mel) : d_melspec_out;
 
-    rc = launch_front(plan, d_pcm, d_sample_offsets, d_frame_offsets, d_group, n_utts, total_frames,
+    rc = launch_front(plan, d_pcm, pcm16, d_sample_offsets, d_frame_offsets, d_group, n_utts, total_frames,
                       mel, nullptr, ws, L, st);
     if (rc != MFCC_OK) return rc;
 
@@ -737,6 +745,22 @@ int mfcc_execute(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sam
     if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[2], st));
     HIP_TRY(hipGetLastError());
     return MFCC_OK;
+}
+
+int mfcc_execute(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sample_offsets,
+                 const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
+                 int64_t total_frames, float* d_out, float* d_melspec_out, void* d_workspace,
+                 size_t workspace_bytes, void* stream) {
+    return execute_impl(plan, d_pcm, false, d_sample_offsets, d_frame_offsets, d_group, n_utts, total_frames,
+                        d_out, d_melspec_out, d_workspace, workspace_bytes, stream);
+}
+
+int mfcc_execute_pcm16(const mfcc_plan* plan, const int16_t* d_pcm16, const int64_t* d_sample_offsets,
+                       const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
+                       int64_t total_frames, float* d_out, float* d_melspec_out, void* d_workspace,
+                       size_t workspace_bytes, void* stream) {
+    return execute_impl(plan, d_pcm16, true, d_sample_offsets, d_frame_offsets, d_group, n_utts, total_frames,
+                        d_out, d_melspec_out, d_workspace, workspace_bytes, stream);
 }
 
 int mfcc_plan_set_profiling(mfcc_plan* plan, int enable) {
@@ -768,7 +792,7 @@ int mfcc_execute_spectrogram(const mfcc_plan* plan, const float* d_pcm,
         return fail(MFCC_E_WORKSPACE, "workspace too small: need " + std::to_string(L.total) + " bytes");
     if (reinterpret_cast<uintptr_t>(d_workspace) % 256)
         return fail(MFCC_E_INVALID, "workspace must be 256-byte aligned");
-    return launch_front(plan, d_pcm, d_sample_offsets, d_frame_offsets, nullptr, n_utts, total_frames,
+    return launch_front(plan, d_pcm, false, d_sample_offsets, d_frame_offsets, nullptr, n_utts, total_frames,
                         nullptr, d_spec_out, static_cast<char*>(d_workspace), L,
                         static_cast<hipStream_t>(stream));
 }

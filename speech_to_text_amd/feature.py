@@ -95,16 +95,18 @@ class MfccPlan:
                 out: Optional[torch.Tensor] = None, melspec_out: Optional[torch.Tensor] = None,
                 workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Run the whole pipeline on device-resident buffers; asynchronous on the current
-        stream.  Returns the (total_frames, n_mfcc) float32 tensor."""
+        stream.  Returns the (total_frames, n_mfcc) float32 tensor.  ``pcm`` is float32, or int16
+        PCM (value / 32768, the waveform torchaudio decodes LibriSpeech FLAC into)."""
         n_utts = sample_offsets.numel() - 1
-        assert pcm.dtype == torch.float32 and pcm.is_contiguous() and pcm.device == self.device
+        assert pcm.dtype in (torch.float32, torch.int16) and pcm.is_contiguous() and pcm.device == self.device
+        fn = _lib.lib().mfcc_execute if pcm.dtype == torch.float32 else _lib.lib().mfcc_execute_pcm16
         assert sample_offsets.dtype == torch.int64 and frame_offsets.dtype == torch.int64
         if out is None:
             out = torch.empty((total_frames, self.config.n_mfcc), dtype=torch.float32, device=self.device)
         ws = workspace if workspace is not None else self.workspace(total_frames, n_utts)
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            _lib.check(_lib.lib().mfcc_execute(
+            _lib.check(fn(
                 self._handle, pcm.data_ptr(), sample_offsets.data_ptr(), frame_offsets.data_ptr(),
                 group.data_ptr() if group is not None else None, n_utts, int(total_frames),
                 out.data_ptr(), melspec_out.data_ptr() if melspec_out is not None else None,
@@ -165,11 +167,17 @@ def _valid_audio(y) -> None:
         raise ParameterError("Audio buffer is not finite everywhere")
 
 
-def _upload_ragged(chans: Sequence, device) -> (torch.Tensor, np.ndarray):
+def _upload_ragged(chans: Sequence, device, dtype=np.float32) -> (torch.Tensor, np.ndarray):
     lens = np.array([int(c.shape[-1]) for c in chans], dtype=np.int64)
     so = np.zeros(len(chans) + 1, dtype=np.int64)
     np.cumsum(lens, out=so[1:])
     total = int(so[-1])
+    if dtype == np.int16:
+        host = np.empty(max(total, 1), dtype=np.int16)
+        host[:1] = 0
+        for c, a, b in zip(chans, so[:-1], so[1:]):
+            host[a:b] = np.asarray(c).reshape(-1)
+        return torch.from_numpy(host).to(device), so
     if all(isinstance(c, torch.Tensor) and c.is_cuda for c in chans) and len(chans) > 0:
         pcm = torch.cat([c.reshape(-1).to(device=device, dtype=torch.float32) for c in chans]) if total else \
             torch.empty(0, dtype=torch.float32, device=device)
@@ -193,7 +201,8 @@ def _run_batch(chans: Sequence, config: MfccConfig, *, groups: Optional[np.ndarr
                           stacklevel=3)
         if config.center and config.pad_mode == "reflect" and c.shape[-1] == 0:
             raise ParameterError("can't extend an empty signal with pad_mode='reflect'")
-    pcm, so = _upload_ragged(chans, plan.device)
+    pcm16 = len(chans) > 0 and all(isinstance(c, np.ndarray) and c.dtype == np.int16 for c in chans)
+    pcm, so = _upload_ragged(chans, plan.device, np.int16 if pcm16 else np.float32)
     fo = plan.frame_offsets(so)
     total_frames = int(fo[-1])
     d_so = torch.from_numpy(so).to(plan.device)
@@ -286,19 +295,25 @@ def mfcc_batch(ys: Sequence, *, sr=22050, n_mfcc=20, dct_type=2, norm="ortho", l
     """Ragged batch: ``ys`` is a sequence of mono utterances, each ``(T_i,)`` or ``(1, T_i)``
     (the waveform layout of a LibriSpeech item, /root/reference/src/preprocess.py:132).
 
+    If every utterance is a numpy int16 array the batch is taken as 16-bit PCM (sample value
+    ``y / 32768``, what torchaudio decodes LibriSpeech FLAC into): half the upload, same result
+    as the float32 waveform.  (``mfcc`` itself stays strict, like librosa: floating point only.)
+
     Returns one ``(n_frames_i, n_mfcc)`` float32 C-contiguous array per utterance -- exactly
     ``librosa.feature.mfcc(y=y_i, ...)[0].T`` as written to HDF5 at
     /root/reference/src/preprocess.py:135-139.  Each utterance has its own top_db maximum.
     """
     config = _split_kwargs(sr, n_mfcc, dct_type, norm, lifter, kwargs)
     chans = []
+    pcm16 = len(ys) > 0 and all(isinstance(y, np.ndarray) and y.dtype == np.int16 for y in ys)
     for y in ys:
-        y = _as_float_array(y)
+        if not pcm16:
+            y = _as_float_array(y)
         if y.ndim == 2 and y.shape[0] == 1:
             y = y[0]
         if y.ndim != 1:
             raise ParameterError(f"mfcc_batch takes mono utterances, got shape {tuple(y.shape)}")
-        if validate:
+        if validate and not pcm16:
             _valid_audio(y)
         chans.append(y)
     if not chans:

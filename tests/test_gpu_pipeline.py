@@ -120,3 +120,32 @@ def test_asr_frontend_with_cmvn(gpu):
         S.cmvn.apply(allf, stats)
         w = np.concatenate(want).astype(np.float64)
         np.testing.assert_allclose(allf.cpu().numpy(), (w - w.mean(0)) / w.std(0), rtol=0, atol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(n_fft=2048, hop_length=512, n_mfcc=13),
+    dict(n_fft=2048, hop_length=512, n_mfcc=13, pad_mode="reflect"),
+    dict(n_fft=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
+])
+def test_int16_pcm_ingest_is_bit_identical(gpu, kw):
+    """16-bit PCM in (value / 32768, the waveform torchaudio decodes a LibriSpeech FLAC into for
+    /root/reference/src/preprocess.py:132-134) gives exactly the float32 path's output."""
+    import warnings
+
+    import speech_to_text_amd as S
+
+    rng = np.random.default_rng(7)
+    lens = [40000, 3, 2047, 2048, 70001, 1]
+    ys16 = [np.round(np.clip(speech_like(n, seed=20 + i), -0.999, 0.999) * 32767).astype(np.int16)
+            for i, n in enumerate(lens)]
+    ys16[1][:] = [-32768, 32767, 0]                     # the extremes of the grid
+    ysf = [y.astype(np.float32) / 32768.0 for y in ys16]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = S.mfcc_batch(ys16, **kw)
+        b = S.mfcc_batch(ysf, **kw)
+    assert len(a) == len(b) == len(lens)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(x, y)
+    del rng

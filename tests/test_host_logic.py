@@ -125,3 +125,15 @@ def test_preprocessor_process_audio_and_sharding(tmp_path):
                           hdf5_backend="min", max_batch_seconds=1.0).preprocess(verbose=False)
     assert n == 9 and len(list((tmp_path / "two").iterdir())) == 9
     assert Preprocessor(None, out_dir=tmp_path / "none").preprocess(verbose=False) == 0
+
+
+def test_int16_ingest_conversion():
+    """Preprocessor(ingest='int16'): only waveforms on the int16 grid are converted."""
+    from speech_to_text_amd.preprocess import to_int16_pcm
+
+    pcm = np.array([-32768, -1, 0, 1, 32767], dtype=np.int16)
+    assert np.array_equal(to_int16_pcm(pcm.astype(np.float32) / 32768.0), pcm)
+    assert to_int16_pcm(pcm) is not None and to_int16_pcm(pcm).dtype == np.int16
+    assert to_int16_pcm(np.array([0.1], dtype=np.float32)) is None            # off the grid
+    assert to_int16_pcm(np.array([1.0], dtype=np.float32)) is None            # 32768 does not fit
+    assert to_int16_pcm(np.zeros((1, 0), dtype=np.float32)).size == 0
