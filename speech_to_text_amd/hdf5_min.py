@@ -70,84 +70,155 @@ def _object_header(messages: bytes, n_messages: int) -> bytes:
 
 
 # ---- writer -----------------------------------------------------------------------------------
-def write_features(path, data: np.ndarray, attrs: Dict[str, AttrValue], name: str = "mfccs") -> None:
-    """Write one dataset ``name`` (float32, C-contiguous, any rank >= 1) with scalar attributes
-    (Python int -> int64, str -> variable-length UTF-8) to a new HDF5 file at ``path``."""
-    data = np.ascontiguousarray(data, dtype="<f4")
-    nm = name.encode("utf-8") + b"\x00"
+GCOL_MAX_OBJECTS = 60000          # object indices in a global heap collection are 16-bit
+GCOL_MAX_BYTES = 1 << 26
+
+
+class _StringHeap:
+    """Variable-length strings go to global heap collections placed after the object headers."""
+
+    def __init__(self):
+        self.collections = [[]]       # lists of utf-8 byte strings
+        self.sizes = [16]
+
+    def add(self, raw: bytes):
+        need = 16 + (len(raw) + 7) // 8 * 8
+        if len(self.collections[-1]) >= GCOL_MAX_OBJECTS or self.sizes[-1] + need + 16 > GCOL_MAX_BYTES:
+            self.collections.append([])
+            self.sizes.append(16)
+        self.collections[-1].append(raw)
+        self.sizes[-1] += need
+        return len(self.collections) - 1, len(self.collections[-1]), len(raw)    # (collection, index, length)
+
+    def collection_bytes(self, c: int) -> int:
+        return max(4096, (self.sizes[c] + 16 + 7) // 8 * 8)
+
+    def addresses(self, start: int):
+        out, a = [], start
+        for c in range(len(self.collections)):
+            out.append(a)
+            a += self.collection_bytes(c)
+        return out, a
+
+    def encode(self, c: int) -> bytes:
+        size = self.collection_bytes(c)
+        body = b"".join(struct.pack("<HH4xQ", i, 1, len(raw)) + _pad8(raw)
+                        for i, raw in enumerate(self.collections[c], start=1))
+        free = size - 16 - len(body)
+        return b"GCOL" + struct.pack("<B3xQ", 1, size) + body + struct.pack("<HH4xQ", 0, 0, free) + b"\x00" * (free - 16)
+
+    @property
+    def empty(self) -> bool:
+        return not self.collections[0]
+
+
+def write_datasets(path, datasets) -> None:
+    """Write a new HDF5 file whose root group holds ``datasets``: an iterable of
+    ``(name, data, attrs)`` with at most eight entries.  ``data`` is a float32 or int64 array
+    (stored C-contiguous) or a list of str (a 1-D variable-length UTF-8 dataset); ``attrs`` maps
+    names to Python ints (int64 scalars) or strs (variable-length UTF-8 scalars)."""
+    datasets = sorted(((n, d, dict(a or {})) for n, d, a in datasets), key=lambda t: t[0].encode("utf-8"))
+    if not 1 <= len(datasets) <= 8:
+        raise ValueError("between one and eight datasets per file")
+    strings = _StringHeap()
+    prepared = []
+    for name, data, attrs in datasets:
+        if isinstance(data, (list, tuple)) and all(isinstance(x, str) for x in data):
+            refs = [strings.add(x.encode("utf-8")) for x in data]
+            prepared.append(dict(name=name, kind="str", shape=(len(refs),), refs=refs, nbytes=16 * len(refs), attrs=attrs))
+        else:
+            arr = np.asarray(data)
+            if arr.dtype.kind == "f":
+                arr, kind = np.ascontiguousarray(arr, dtype="<f4"), "f32"
+            elif arr.dtype.kind in "iu":
+                arr, kind = np.ascontiguousarray(arr, dtype="<i8"), "i64"
+            else:
+                raise TypeError(f"dataset {name!r}: unsupported dtype {arr.dtype}")
+            prepared.append(dict(name=name, kind=kind, shape=arr.shape, arr=arr, nbytes=arr.nbytes, attrs=attrs))
+        aref = {}
+        for k, v in attrs.items():
+            if isinstance(v, str):
+                aref[k] = strings.add(v.encode("utf-8"))
+            elif not (isinstance(v, (int, np.integer)) and not isinstance(v, bool)):
+                raise TypeError(f"attribute {k!r}: only int and str are supported, got {type(v).__name__}")
+        prepared[-1]["aref"] = aref
+
+    def dataset_header(d, gaddr, a_data) -> bytes:
+        dt = {"f32": _dt_f32(), "i64": _dt_i64(), "str": _dt_vlen_utf8()}[d["kind"]]
+        msgs = [
+            _message(0x0001, _ds_simple(d["shape"])),
+            _message(0x0003, dt, flags=1),                           # constant message
+            _message(0x0005, struct.pack("<BBBBI", 2, 2, 2, 1, 0)),  # fill value: default, alloc late
+            _message(0x0008, struct.pack("<BBQQ", 3, 1, a_data if d["nbytes"] else UNDEF, d["nbytes"])),
+        ]
+        for k, v in d["attrs"].items():
+            if isinstance(v, str):
+                c, idx, ln = d["aref"][k]
+                msgs.append(_attribute(k, _dt_vlen_utf8(), _ds_simple(()), struct.pack("<IQI", ln, gaddr[c], idx)))
+            else:
+                msgs.append(_attribute(k, _dt_i64(), _ds_simple(()), struct.pack("<q", int(v))))
+        return _object_header(b"".join(msgs), len(msgs))
 
     # fixed-size pieces first, to know the addresses
     SB, ROOT_OH, BTREE, HEAP_HDR, SNOD = 96, 40, 544, 32, 328
-    heap_data = _pad8(b"\x00" * 8 + nm)
-    heap_data += struct.pack("<QQ", 1, 16)                       # one free block closing the segment
+    heap_data, name_off = b"\x00" * 8, []
+    for d in prepared:
+        name_off.append(len(heap_data))
+        heap_data += _pad8(d["name"].encode("utf-8") + b"\x00")
+    heap_data += struct.pack("<QQ", 1, 16)                           # one free block closing the segment
     a_root = SB
     a_btree = a_root + ROOT_OH
     a_heap = a_btree + BTREE
     a_heap_data = a_heap + HEAP_HDR
     a_snod = a_heap_data + len(heap_data)
-    a_dset = a_snod + SNOD
-
-    # global heap for variable-length strings
-    strings = [(k, v.encode("utf-8")) for k, v in attrs.items() if isinstance(v, str)]
-    gheap_objs = b""
-    str_index = {}
-    for i, (k, raw) in enumerate(strings, start=1):
-        str_index[k] = (i, len(raw))
-        gheap_objs += struct.pack("<HH4xQ", i, 1, len(raw)) + _pad8(raw)
-
-    def dataset_header(a_gheap: int, a_data: int) -> bytes:
-        msgs = [
-            _message(0x0001, _ds_simple(data.shape)),
-            _message(0x0003, _dt_f32(), flags=1),                # constant message
-            _message(0x0005, struct.pack("<BBBBI", 2, 2, 2, 1, 0)),   # fill value: default, alloc late
-            _message(0x0008, struct.pack("<BBQQ", 3, 1, a_data if data.nbytes else UNDEF, data.nbytes)),
-        ]
-        for k, v in attrs.items():
-            if isinstance(v, str):
-                idx, ln = str_index[k]
-                msgs.append(_attribute(k, _dt_vlen_utf8(), _ds_simple(()), struct.pack("<IQI", ln, a_gheap, idx)))
-            elif isinstance(v, (int, np.integer)) and not isinstance(v, bool):
-                msgs.append(_attribute(k, _dt_i64(), _ds_simple(()), struct.pack("<q", int(v))))
-            else:
-                raise TypeError(f"attribute {k!r}: only int and str are supported, got {type(v).__name__}")
-        return _object_header(b"".join(msgs), len(msgs))
-
-    dset_len = len(dataset_header(0, 0))
-    a_gheap = a_dset + dset_len
-    gheap = b""
-    if strings:
-        size = max(4096, (16 + len(gheap_objs) + 16 + 7) // 8 * 8)
-        free = size - 16 - len(gheap_objs)
-        gheap = b"GCOL" + struct.pack("<B3xQ", 1, size) + gheap_objs
-        gheap += struct.pack("<HH4xQ", 0, 0, free) + b"\x00" * (free - 16)
-    a_data = a_gheap + len(gheap)
-    dset = dataset_header(a_gheap, a_data)
-    eof = a_data + data.nbytes
+    a = a_snod + SNOD
+    a_dset = []
+    dummy = [0] * len(strings.collections)
+    for d in prepared:
+        a_dset.append(a)
+        a += len(dataset_header(d, dummy, 0))
+    gaddr, a = strings.addresses(a) if not strings.empty else ([], a)
+    a_data = []
+    for d in prepared:
+        a_data.append(a)
+        a += (d["nbytes"] + 7) // 8 * 8
+    eof = a
 
     sb = SIGNATURE + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, 4, 16, 0)
     sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
     sb += struct.pack("<QQI4xQQ", 0, a_root, 1, a_btree, a_heap)     # root symbol-table entry
     assert len(sb) == SB
-
     root = _object_header(_message(0x0011, struct.pack("<QQ", a_btree, a_heap)), 1)
     assert len(root) == ROOT_OH
-
-    off_name = 8
     btree = b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, UNDEF, UNDEF)
-    btree += struct.pack("<QQQ", 0, a_snod, off_name)
+    btree += struct.pack("<QQQ", 0, a_snod, name_off[-1])            # keys: "" and the largest name
     btree += b"\x00" * (BTREE - len(btree))
-
     heap = b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), len(heap_data) - 16, a_heap_data)
     assert len(heap) == HEAP_HDR
-
-    snod = b"SNOD" + struct.pack("<BxH", 1, 1)
-    snod += struct.pack("<QQI4x16x", off_name, a_dset, 0)
+    snod = b"SNOD" + struct.pack("<BxH", 1, len(prepared))
+    for off, ad in zip(name_off, a_dset):
+        snod += struct.pack("<QQI4x16x", off, ad, 0)
     snod += b"\x00" * (SNOD - len(snod))
 
     with open(path, "wb") as f:
-        for part in (sb, root, btree, heap, heap_data, snod, dset, gheap):
+        for part in (sb, root, btree, heap, heap_data, snod):
             f.write(part)
-        f.write(data.tobytes())
+        for d, ad in zip(prepared, a_data):
+            f.write(dataset_header(d, gaddr or dummy, ad))
+        for c in range(len(gaddr)):
+            f.write(strings.encode(c))
+        for d in prepared:
+            if d["kind"] == "str":
+                raw = b"".join(struct.pack("<IQI", ln, gaddr[c], idx) for c, idx, ln in d["refs"])
+            else:
+                raw = d["arr"].tobytes()
+            f.write(raw + b"\x00" * (-len(raw) % 8))
+
+
+def write_features(path, data: np.ndarray, attrs: Dict[str, AttrValue], name: str = "mfccs") -> None:
+    """Write one dataset ``name`` (float32, C-contiguous, any rank >= 1) with scalar attributes
+    (Python int -> int64, str -> variable-length UTF-8) to a new HDF5 file at ``path``."""
+    write_datasets(path, [(name, np.ascontiguousarray(data, dtype="<f4"), attrs)])
 
 
 # ---- reader -----------------------------------------------------------------------------------
@@ -157,6 +228,7 @@ class _Reader:
         if buf[:8] != SIGNATURE or buf[8] != 0 or buf[13] != 8 or buf[14] != 8:
             raise ValueError("not a version-0-superblock HDF5 file with 8-byte offsets")
         self.root_btree, self.root_heap = struct.unpack_from("<QQ", buf, 24 + 32 + 24)
+        self._gcol = {}
 
     def _heap_name(self, heap_addr: int, off: int) -> str:
         seg = struct.unpack_from("<Q", self.b, heap_addr + 24)[0]
@@ -207,30 +279,43 @@ class _Reader:
             return raw[:size].split(b"\x00")[0].decode("utf-8")
         if cls == 9:
             ln, addr, idx = struct.unpack_from("<IQI", raw)
-            assert self.b[addr:addr + 4] == b"GCOL"
-            p = addr + 16
-            while True:
-                i, _, osz = struct.unpack_from("<HH4xQ", self.b, p)
-                if i == idx:
-                    return self.b[p + 16:p + 16 + ln].decode("utf-8")
-                if i == 0:
-                    raise ValueError("global heap object not found")
-                p += 16 + (osz + 7) // 8 * 8
+            index = self._gcol.get(addr)
+            if index is None:                 # object index -> data offset, one pass per collection
+                assert self.b[addr:addr + 4] == b"GCOL"
+                index, p = {}, addr + 16
+                end = addr + struct.unpack_from("<Q", self.b, addr + 8)[0]
+                while p + 16 <= end:
+                    i, _, osz = struct.unpack_from("<HH4xQ", self.b, p)
+                    if i == 0:
+                        break
+                    index[i] = p + 16
+                    p += 16 + (osz + 7) // 8 * 8
+                self._gcol[addr] = index
+            if idx not in index:
+                raise ValueError("global heap object not found")
+            return self.b[index[idx]:index[idx] + ln].decode("utf-8")
         raise ValueError(f"unsupported attribute datatype class {cls}")
+
+    def names(self):
+        return [nm for nm, _ in self._group_entries(self.root_btree, self.root_heap)]
 
     def dataset(self, name: str):
         for nm, oh in self._group_entries(self.root_btree, self.root_heap):
             if nm != name:
                 continue
-            shape, dtype, addr, attrs = None, None, None, {}
+            shape, dtype, addr, attrs, vlen = None, None, None, {}, None
             for mtype, body in self._messages(oh):
                 if mtype == 0x0001:
                     rank = body[1]
                     shape = struct.unpack_from(f"<{rank}Q", body, 8) if rank else ()
                 elif mtype == 0x0003:
-                    if (body[0] & 0x0F) != 1 or body[1] & 1:
-                        raise ValueError("dataset is not little-endian floating point")
-                    dtype = np.dtype(f"<f{struct.unpack_from('<I', body, 4)[0]}")
+                    cls, size = body[0] & 0x0F, struct.unpack_from("<I", body, 4)[0]
+                    if cls == 9:
+                        vlen = bytes(body)
+                    elif body[1] & 1 or cls not in (0, 1):
+                        raise ValueError("dataset is not little-endian integer, floating point or vlen string")
+                    else:
+                        dtype = np.dtype(f"<f{size}") if cls == 1 else np.dtype(f"<{'i' if body[1] & 0x08 else 'u'}{size}")
                 elif mtype == 0x0008:
                     if body[0] != 3 or body[1] != 1:
                         raise ValueError("only contiguous version-3 layouts are supported")
@@ -244,10 +329,23 @@ class _Reader:
                     p += (dsz + 7) // 8 * 8 + (ssz + 7) // 8 * 8
                     attrs[aname] = self._decode(adt, body[p:])
             n = int(np.prod(shape)) if shape else 1
+            if vlen is not None:
+                return [self._decode(vlen, self.b[addr + 16 * i:addr + 16 * i + 16]) for i in range(n)], attrs
             arr = np.frombuffer(self.b, dtype=dtype, count=n, offset=addr).reshape(shape) if n else \
                 np.zeros(shape, dtype=dtype)
             return arr.copy(), attrs
         raise KeyError(name)
+
+
+def read_dataset(path, name: str):
+    """(values, attrs) of any dataset written by write_datasets: a numpy array, or a list of str."""
+    with open(path, "rb") as f:
+        return _Reader(f.read()).dataset(name)
+
+
+def list_datasets(path):
+    with open(path, "rb") as f:
+        return _Reader(f.read()).names()
 
 
 def read_features(path, name: str = "mfccs"):

@@ -144,9 +144,11 @@ class Preprocessor:
         frames = self._features([samples])[0]          # == librosa.feature.mfcc(y=samples)[0].T
         self._write(item, frames)
 
-    def preprocess(self, multiprocess: bool = False, verbose: bool = True) -> int:
+    def preprocess(self, multiprocess: bool = False, verbose: bool = True, packed: bool = False) -> int:
         """/root/reference/src/preprocess.py:146-167: every item of ``self.data`` -> one file.
-        Returns the number of files this rank wrote."""
+        Returns the number of utterances this rank wrote.  While the writer threads store batch
+        k the GPU already works on batch k + 1.  ``packed=True`` writes this rank's utterances to
+        one file ``out_dir/packed_{rank:05d}.hdf5`` instead (sink.write_packed)."""
         if self.data is None:
             print("Data is empty. Aborted.")
             return 0
@@ -162,6 +164,7 @@ class Preprocessor:
             print(f"Processing audio data... rank {self.rank}/{self.world_size}: {len(mine)} of {len(items)} "
                   f"utterances in {len(batches)} GPU batch(es), {n_threads} writer thread(s)")
         done = 0
+        kept, kept_idx = [], []
         with ThreadPoolExecutor(max_workers=n_threads) as pool:
             pending = []
             for b in batches:
@@ -169,12 +172,23 @@ class Preprocessor:
                 feats = self._features([_waveform_to_numpy(items[i][0]) for i in idx])
                 for f in pending:
                     f.result()
-                pending = [pool.submit(self._write, items[i], fr) for i, fr in zip(idx, feats)]
+                if packed:
+                    kept.extend(feats)
+                    kept_idx.extend(int(i) for i in idx)
+                    pending = []
+                else:
+                    pending = [pool.submit(self._write, items[i], fr) for i, fr in zip(idx, feats)]
                 done += len(idx)
                 if verbose:
                     print(f"Progress: {done}/{len(mine)}", end="\r")
             for f in pending:
                 f.result()
+        if packed:
+            from .sink import write_packed
+
+            metas = [dict(sample_rate=items[i][1], transcript=items[i][2], speaker_id=items[i][3],
+                          chapter_id=items[i][4], utterance_id=items[i][5]) for i in kept_idx]
+            write_packed(self.out_dir / f"packed_{self.rank:05d}.hdf5", kept, metas, backend=self.hdf5_backend)
         if verbose:
             print()
         return done

@@ -149,3 +149,29 @@ def test_int16_pcm_ingest_is_bit_identical(gpu, kw):
     for x, y in zip(a, b):
         assert x.shape == y.shape and np.array_equal(x, y)
     del rng
+
+
+def test_packed_sink_int16_ingest_and_device_dataset(gpu, tmp_path):
+    """The packed single-file sink (fed through the int16 ingest) and the dataset that hands the
+    trainer device-resident features give the same numbers as the per-utterance path."""
+    import torch
+
+    import speech_to_text_amd as S
+
+    lens = ragged_lengths(10, 0.5, 4.0, seed=9)
+    items = [(speech_like(int(L), seed=60 + i, int16_grid=True)[None, :], 16000, f"UTTERANCE {i}", 100 + i, 200 + i, i)
+             for i, L in enumerate(lens)]
+    pre = S.Preprocessor(items, out_dir=tmp_path / "p", hdf5_backend="min", max_batch_seconds=10.0, ingest="int16")
+    assert pre.preprocess(verbose=False, packed=True) == 10
+    rd = S.PackedReader(tmp_path / "p" / "packed_00000.hdf5")
+    ref = S.mfcc_batch([it[0] for it in items], n_fft=2048, hop_length=512, n_mfcc=13)     # float32 path
+    by_utt = {attrs["utterance_id"]: arr for arr, attrs in rd}
+    for i, it in enumerate(items):
+        assert np.array_equal(by_utt[i], ref[i])                       # int16 ingest is bit-identical
+        np.testing.assert_allclose(by_utt[i], R.process_audio_features(it[0]), rtol=0, atol=1e-2)
+    ds = S.FeatureDataset(items, device=gpu, max_batch_seconds=10.0)
+    assert len(ds) == 10
+    for i in range(10):
+        mf, sr, text, spk = ds[i]
+        assert isinstance(mf, torch.Tensor) and mf.is_cuda and tuple(mf.shape) == ref[i].shape
+        assert np.array_equal(mf.cpu().numpy(), ref[i]) and (sr, text, spk) == (16000, f"UTTERANCE {i}", 100 + i)

@@ -137,3 +137,73 @@ def test_int16_ingest_conversion():
     assert to_int16_pcm(np.array([0.1], dtype=np.float32)) is None            # off the grid
     assert to_int16_pcm(np.array([1.0], dtype=np.float32)) is None            # 32768 does not fit
     assert to_int16_pcm(np.zeros((1, 0), dtype=np.float32)).size == 0
+
+
+# ---- packed file, trainer-side readers, direct dataset -------------------------------------------------
+def test_packed_file_round_trip_and_h5dump(tmp_path):
+    from speech_to_text_amd import PackedReader, load_training_items
+
+    items = make_items(6, seed=5)
+    n = Preprocessor(items, out_dir=tmp_path / "p", extractor=oracle_extractor, hdf5_backend="min",
+                     max_batch_seconds=1.0).preprocess(verbose=False, packed=True)
+    assert n == 6
+    path = tmp_path / "p" / "packed_00000.hdf5"
+    rd = PackedReader(path)
+    assert len(rd) == 6
+    seen = {}
+    for arr, attrs in rd:
+        seen[attrs["utterance_id"]] = (arr, attrs)
+    for i, it in enumerate(items):
+        arr, attrs = seen[i]
+        assert np.array_equal(arr, R.process_audio_features(it[0])) and arr.dtype == np.float32
+        assert attrs == dict(speaker_id=1000 + i, chapter_id=2000 + i, utterance_id=i, sample_rate=16000,
+                             transcript=f"TRANSCRIPT NUMBER {i} ü")
+    data = load_training_items(path)          # what /root/reference/src/trainer.py:104-114 builds
+    assert len(data) == 6 and all(len(d) == 4 and d[1] == 16000 and d[2].startswith("TRANSCRIPT") for d in data)
+    with pytest.raises(IndexError):
+        rd[6]
+    import shutil, subprocess
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if shutil.os.path.exists("/opt/conda/bin/h5dump") else None)
+    if h5dump is not None:                    # libhdf5's own reader accepts the file
+        out = subprocess.run([h5dump, "-H", str(path)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        for name in ("mfccs", "frame_offsets", "speaker_id", "chapter_id", "utterance_id", "sample_rate", "transcript"):
+            assert f'DATASET "{name}"' in out.stdout
+        assert "H5T_IEEE_F32LE" in out.stdout and "H5T_VARIABLE" in out.stdout
+
+
+def test_load_training_items_from_per_utterance_files(tmp_path):
+    from speech_to_text_amd import load_training_items
+
+    items = make_items(4, seed=6)
+    Preprocessor(items, out_dir=tmp_path / "mfcc", extractor=oracle_extractor, hdf5_backend="min").preprocess(verbose=False)
+    data = load_training_items(tmp_path / "mfcc")
+    assert len(data) == 4
+    by_spk = {d[3]: d for d in data}
+    for i, it in enumerate(items):
+        d = by_spk[1000 + i]
+        assert np.array_equal(d[0], R.process_audio_features(it[0])) and d[2] == f"TRANSCRIPT NUMBER {i} ü"
+    assert len(load_training_items(tmp_path / "mfcc", num_files=2)) == 2
+
+
+def test_feature_dataset_matches_trainer_item_layout():
+    from speech_to_text_amd import FeatureDataset
+
+    items = make_items(5, seed=8)
+    ds = FeatureDataset(items, extractor=oracle_extractor, max_batch_seconds=1.0)
+    assert len(ds) == 5
+    for i, it in enumerate(items):
+        mf, sr, text, spk = ds[i]
+        assert np.array_equal(np.asarray(mf), R.process_audio_features(it[0]))
+        assert (sr, text, spk) == (16000, f"TRANSCRIPT NUMBER {i} ü", 1000 + i)
+
+
+def test_hdf5_min_many_strings_span_collections(tmp_path):
+    texts = [f"utterance {i} " + "x" * (i % 50) for i in range(70000)]     # > 65535 heap objects
+    hdf5_min.write_datasets(tmp_path / "s.hdf5", [("transcript", texts, None), ("ids", np.arange(70000), {"k": 3})])
+    got, _ = hdf5_min.read_dataset(tmp_path / "s.hdf5", "transcript")
+    assert got == texts
+    ids, attrs = hdf5_min.read_dataset(tmp_path / "s.hdf5", "ids")
+    assert np.array_equal(ids, np.arange(70000)) and attrs == {"k": 3}
+    with pytest.raises(ValueError):
+        hdf5_min.write_datasets(tmp_path / "n.hdf5", [(f"d{i}", np.zeros(1, np.float32), None) for i in range(9)])
