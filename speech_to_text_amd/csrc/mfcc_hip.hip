@@ -191,6 +191,68 @@ __global__ __launch_bounds__(256) void k_db_dct(const DbDctArgs a) {
     }
 }
 
+// The reference's shape (128 mels, at most 16 coefficients, 16-byte aligned rows): persistent
+// wavefronts keep the DCT fragments in registers, have a whole tile's eight 16-byte loads in
+// flight at once and request the next tile's before working on the current one.
+__global__ __launch_bounds__(256) void k_db_dct_128(const DbDctArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_tiles = a.hdr->n_tiles;
+    const int n_waves = gridDim.x * 4;
+    const int f = lane & 15, kq = lane >> 4;
+    float frag[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) frag[s] = a.dct_frag[s * 64 + lane];
+    float lift[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lift[i] = (4 * kq + i < a.n_mfcc) ? a.lifter[4 * kq + i] : 0.0f;
+
+    auto load_tile = [&](int tile, Tile& ti, float4 (&t)[8]) {
+        ti = a.tiles[tile];
+        const int nvalid = min(TILE_FRAMES, ti.F - ti.f0);
+        const float* mrow = a.mel + (ti.row0 + min(f, nvalid - 1)) * 128 + 4 * kq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4*>(mrow + 16 * j);
+    };
+
+    int tile = blockIdx.x * 4 + wave;
+    if (tile >= n_tiles) return;
+    Tile ti, ti_n;
+    float4 t[8], tn[8];
+    load_tile(tile, ti, t);
+    for (; tile < n_tiles; tile += n_waves) {
+        const bool more = tile + n_waves < n_tiles;
+        if (more) load_tile(tile + n_waves, ti_n, tn);
+        float thr = -INFINITY;
+        if (a.top_db >= 0.0f) {
+            const float gm = __uint_as_float(a.gmax[ti.grp]);
+            thr = 10.0f * log10f(fmaxf(a.amin, gm)) - a.ref_db - a.top_db;
+        }
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v[4] = {t[j].x, t[j].y, t[j].z, t[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float db = fmaxf(10.0f * log10f(fmaxf(a.amin, v[i])) - a.ref_db, thr);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[4 * j + i], db, acc, 0, 0, 0);
+            }
+        }
+        const int nvalid = min(TILE_FRAMES, ti.F - ti.f0);
+        if (f < nvalid) {
+            float* orow = a.out + (ti.row0 + f) * a.n_mfcc;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * kq + i < a.n_mfcc) orow[4 * kq + i] = acc[i] * lift[i];
+        }
+        if (more) {
+            ti = ti_n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = tn[j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // CMVN statistics (extension)
 // ------------------------------------------------------------------------------------------
@@ -741,7 +803,12 @@ static int execute_impl(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     da.vec_ok = (plan->r.c.n_mels % 4 == 0) && (reinterpret_cast<uintptr_t>(mel) % 16 == 0);
     da.amin = plan->r.c.amin; da.ref_db = plan->ref_db; da.top_db = plan->r.c.top_db;
     const int blocks = (int)((L.ub_tiles + 3) / 4);
-    hipLaunchKernelGGL(k_db_dct, dim3(blocks), dim3(256), 0, st, da);
+    if (da.vec_ok && da.n_mels == 128 && da.n_mfcc <= 16) {
+        const int grid = std::max(1, std::min(blocks, plan->n_cu * 8));
+        hipLaunchKernelGGL(k_db_dct_128, dim3(grid), dim3(256), 0, st, da);
+    } else {
+        hipLaunchKernelGGL(k_db_dct, dim3(blocks), dim3(256), 0, st, da);
+    }
     if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[2], st));
     HIP_TRY(hipGetLastError());
     return MFCC_OK;
