@@ -170,13 +170,21 @@ def main():
                          f"(WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
+    # BENCH_REHEARSAL=1: several ranks share the GPUs that exist and talk over gloo -- a dry run of
+    # the multi-rank code path on a one-GPU machine, not a measurement.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import speech_to_text_amd as S
 

@@ -559,6 +559,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             for (uint32_t m = a.mel_zero_rows; m; m &= m - 1)
                 X[MCELL_OFF + 64 * __builtin_ctz(m) + lane] = 0.0f;
         }
+        // This lane's job descriptors are requested here so that they return while column 0
+        // makes its round trip.
+        const bool mel_fast = MELW_LDS && n_jobs <= MEL_REG_JOBS && a.mel_out && !(a.ablate & 1);
+        uint4 jq = make_uint4(0u, 0u, 0u, 0u);
+        if (mel_fast) jq = reinterpret_cast<const uint4*>(jobs_l)[lane];
         {
             // column 0: C = DFT-64 of c[r] = y[2r] + i y[2r+1]; Y[j] = E[j] + W_128^j O[j]
             const float2* S = reinterpret_cast<const float2*>(X + SPECIAL_OFF);
@@ -611,9 +616,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
                 else __hip_atomic_fetch_add(c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             };
             float chain = 0.0f;
-            if (MELW_LDS && n_jobs <= MEL_REG_JOBS) {
+            if (mel_fast) {
                 // all reads of MEL_BATCH jobs in flight at once (n_jobs == MEL_REG_JOBS here)
-                const uint4 jq = reinterpret_cast<const uint4*>(jobs_l)[lane];
                 const uint32_t jobr[MEL_REG_JOBS] = {jq.x, jq.y, jq.z, jq.w};
 #pragma unroll
                 for (int j = 0; j < MEL_REG_JOBS; j += MEL_BATCH) {
