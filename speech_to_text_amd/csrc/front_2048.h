@@ -79,7 +79,7 @@ enum TableHome { IN_LDS = 0, IN_REGS = 1, IN_GLOBAL = 2 };
 constexpr size_t lds_bytes(int waves, int win, int tw1, bool w64_regs, int melw_floats) {
     return sizeof(float) * ((size_t)waves * XCH_FLOATS + (tw1 == IN_LDS ? TW1_FLOATS : 0) +
                             (w64_regs ? 0 : W64_FLOATS) + (win == IN_LDS ? WIN_FLOATS : 0) +
-                            (size_t)melw_floats);
+                            (size_t)melw_floats + 16 /* slot counters */);
 }
 __host__ __device__ constexpr int p_index(int bin) { return bin + (P_ROW - P_ROW_BINS) * (bin >> 6); }
 }  // namespace k2048
@@ -129,6 +129,7 @@ struct FrontArgs {
     int32_t reflect;
     int32_t pw_mode;         // 0: power 2, 1: power 1, 2: general
     int32_t pcm16;           // pcm holds int16 samples
+    int32_t share;           // wavefronts that walk one run of frames together (1, 2, 4, 8 or 16)
     int32_t ablate;          // development only: bit 0 skips the mel stage
     float half_power;        // power / 2
 };
@@ -255,11 +256,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     if (WIN == IN_LDS) tab += WIN_FLOATS;
     float4* melw_l = reinterpret_cast<float4*>(tab);
     int2* jobs_l = reinterpret_cast<int2*>(melw_l + a.n_jobs * MEL_J * 64);
+    // one slot counter per group of wavefronts that share a run (after the tables)
+    int* run_ctr = MELW_LDS ? reinterpret_cast<int*>(jobs_l + a.n_jobs * 64) : reinterpret_cast<int*>(melw_l);
 
     for (int i = tid; i < WAVES * XCH_FLOATS; i += THREADS) lds[i] = 0.0f;
     if (TW1 == IN_LDS) { for (int i = tid; i < 15 * 64; i += THREADS) tw1_l[i] = a.tw1[i]; }
     if (!W64_REGS) { if (tid < 64) w64_l[(tid >> 4) * W64_STRIDE + (tid & 15)] = a.w64[tid]; }
     if (WIN == IN_LDS) { for (int i = tid; i < 2048; i += THREADS) win_l[i] = a.window[i]; }
+    if (tid < WAVES) run_ctr[tid] = 0;
     if (MELW_LDS) {
         for (int i = tid; i < a.n_jobs * MEL_J * 64; i += THREADS) melw_l[i] = a.melw[i];
         if (a.n_jobs <= MEL_REG_JOBS) {
@@ -322,28 +326,33 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     int cur_grp = -1;
     const int n_tiles = a.hdr->n_tiles;
 
-    // Work unit = one frame slot (tile, frame-in-tile).  Every wavefront of the grid owns one
-    // contiguous run of slots and walks it in order: consecutive frames of a run share 75 % of
-    // their samples, which the wavefront re-reads from L2 a few microseconds later (runs of
-    // different wavefronts do not overlap, so each sample leaves HBM once), and a wavefront
-    // stays within one utterance for many frames (one atomicMax per utterance change).
+    // Work unit = one frame slot (tile, frame-in-tile).  The slots are cut into contiguous runs,
+    // one per group of g = a.share neighbouring wavefronts (g = 1 with HOPR > 0).  The wavefronts
+    // of a group take the slots of their run one at a time from a counter in LDS, so at any moment
+    // they work on neighbouring frames: consecutive frames share 75 % of their samples, the group
+    // keeps one window of samples warm in L2 instead of g, and a wavefront stays within one
+    // utterance for many frames (one atomicMax per utterance change).  The next slot is requested
+    // a frame ahead.  Every wavefront leaves the loop as soon as the counter passes the run's end.
+    const int g = (HOPR > 0 || WAVES % a.share != 0) ? 1 : a.share;
     const int64_t n_slots = (int64_t)n_tiles * TILE_FRAMES;
-    const int64_t n_runs = (int64_t)gridDim.x * WAVES;
+    const int64_t n_runs = (int64_t)gridDim.x * WAVES / g;
     const int64_t per_run = (n_slots + n_runs - 1) / n_runs;
-    const int64_t run = (int64_t)blockIdx.x * WAVES + wave;
-    const int64_t slot0 = run * per_run;
-    const int64_t slot_end = min(n_slots, slot0 + per_run);
+    const int64_t run_base = (((int64_t)blockIdx.x * WAVES + wave) / g) * per_run;
+    const int count = run_base < n_slots ? (int)min(per_run, n_slots - run_base) : 0;
+    int* my_ctr = run_ctr + wave / g;
+    int next_static = 0;
+    auto request_slot = [&]() -> int {     // index within the run; the same in all lanes once read
+        if (g == 1) return next_static++;
+        int v = 0;
+        if (lane == 0) v = atomicAdd(my_ctr, 1);
+        return v;
+    };
 
     // Tile descriptors are read with scalar loads, one tile ahead of the frames being processed,
     // so the frame loop never waits on them (a vector load here would make every frame wait for
     // the previous frame's stores to be acknowledged).
-    int remaining = slot_end > slot0 ? (int)(slot_end - slot0) : 0;
-    int tix = (int)(slot0 >> 4), fr = (int)(slot0 & 15);
+    int tix = -2;
     Tile ti = {}, ti_next = {};
-    if (remaining > 0) {
-        ti = load_tile(a.tiles, tix);
-        ti_next = load_tile(a.tiles, min(tix + 1, n_tiles - 1));
-    }
     auto is_interior = [&](const Tile& c, int tt) -> bool {
         const int start = tt * a.hop - a.pad;
         return start >= 0 && start + NFFT <= c.T;
@@ -391,19 +400,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         }
     };
 
-    for (; remaining > 0; --remaining) {
-        const int t = ti.f0 + fr;
-        const bool valid = t < ti.F;        // the last tile of an utterance may be partly empty
-        // does the next slot of this run hold frame t + 1 of the same utterance?
-        const bool next_same = remaining > 1 &&
-            (fr < TILE_FRAMES - 1 ? t + 1 < ti.F : (ti_next.soff == ti.soff && ti_next.f0 == t + 1));
-        const Tile tc = ti;
-        if (++fr == TILE_FRAMES) {
-            fr = 0;
-            ++tix;
-            ti = ti_next;
+    int next_v = 0;
+    for (int cur = __builtin_amdgcn_readfirstlane(request_slot()); cur < count;
+         cur = __builtin_amdgcn_readfirstlane(next_v)) {
+        next_v = request_slot();
+        const int64_t slot = run_base + cur;
+        const int tidx = (int)(slot >> 4), fr = (int)(slot & 15);
+        if (tidx != tix) {
+            ti = (tidx == tix + 1) ? ti_next : load_tile(a.tiles, tidx);
+            tix = tidx;
             ti_next = load_tile(a.tiles, min(tix + 1, n_tiles - 1));
         }
+        const int t = ti.f0 + fr;
+        const bool valid = t < ti.F;        // the last tile of an utterance may be partly empty
+        // (HOPR > 0, so g = 1) does the next slot of this run hold frame t + 1 of the utterance?
+        const bool next_same = cur + 1 < count &&
+            (fr < TILE_FRAMES - 1 ? t + 1 < ti.F : (ti_next.soff == ti.soff && ti_next.f0 == t + 1));
+        const Tile tc = ti;
         if (!valid) continue;
         const bool interior = is_interior(tc, t);
         if (tc.grp != cur_grp) {

@@ -743,6 +743,13 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     fa.pad = plan->r.c.center ? plan->r.c.n_fft / 2 : 0;
     fa.reflect = plan->r.c.pad_mode == MFCC_PAD_REFLECT;
     fa.ablate = std::getenv("MFCC_HIP_ABLATE") ? std::atoi(std::getenv("MFCC_HIP_ABLATE")) : 0;
+    // four neighbouring wavefronts (one per SIMD) walk one run of frames together: measured
+    // 1.10 x the algorithmic HBM traffic instead of 1.9 x with private runs (MFCC_HIP_SHARE = 1)
+    fa.share = 4;
+    if (const char* e = std::getenv("MFCC_HIP_SHARE")) {
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) fa.share = v;
+    }
     fa.pw_mode = plan->r.c.power == 2.0f ? 0 : (plan->r.c.power == 1.0f ? 1 : 2);
     fa.half_power = 0.5f * plan->r.c.power;
     const FrontVariant& fv = plan->front;
