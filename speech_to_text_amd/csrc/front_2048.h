@@ -327,13 +327,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     const int n_tiles = a.hdr->n_tiles;
 
     // Work unit = one frame slot (tile, frame-in-tile).  The slots are cut into contiguous runs,
-    // one per group of g = a.share neighbouring wavefronts (g = 1 with HOPR > 0).  The wavefronts
+    // one per group of g = a.share neighbouring wavefronts (by default the whole workgroup; g = 1
+    // with HOPR > 0).  The wavefronts
     // of a group take the slots of their run one at a time from a counter in LDS, so at any moment
     // they work on neighbouring frames: consecutive frames share 75 % of their samples, the group
     // keeps one window of samples warm in L2 instead of g, and a wavefront stays within one
     // utterance for many frames (one atomicMax per utterance change).  The next slot is requested
     // a frame ahead.  Every wavefront leaves the loop as soon as the counter passes the run's end.
-    const int g = (HOPR > 0 || WAVES % a.share != 0) ? 1 : a.share;
+    const int g = HOPR > 0 ? 1 : (a.share >= WAVES ? WAVES : (WAVES % a.share != 0 ? 1 : a.share));
     const int64_t n_slots = (int64_t)n_tiles * TILE_FRAMES;
     const int64_t n_runs = (int64_t)gridDim.x * WAVES / g;
     const int64_t per_run = (n_slots + n_runs - 1) / n_runs;
