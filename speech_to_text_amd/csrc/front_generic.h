@@ -8,7 +8,9 @@
 // librosa.feature.mfcc (/root/reference/src/preprocess.py:134) for non-default n_fft.
 //
 // One workgroup (4 wavefronts) per 16-frame tile:
-//   stage   each wavefront windows 4 frames into LDS A[16][lda]
+//   stage   each wavefront windows 4 frames into LDS, laid out so that the four A operands of
+//           four consecutive MFMA steps are one 16-byte read: sample n of frame f sits at float
+//           ((n & 3) * 16 + f) * lda + (n >> 2), lda = 4 * (odd number of quads) (conflict-free)
 //   DFT     wavefront w takes column tiles w, w+4, ...; columns interleave (cos, -sin) so a bin's
 //           real and imaginary parts sit in neighbouring lanes; power by one DPP swap
 //   mel     wavefront w runs the lane-per-filter contraction on frames 4w .. 4w+3 from LDS P
@@ -24,7 +26,7 @@ struct GenArgs {
     const Tile* tiles;
     const WsHeader* hdr;
     const float* window;       // n_fft
-    const float* dfrag;        // [col tile][k step][lane] DFT matrix in MFMA B-fragment order
+    const float* dfrag;        // [col tile][k step / 4][lane][4] DFT matrix in MFMA B-fragment order
     const float4* melw;
     const int32_t* mel_start;
     const int32_t* mel_filt;
@@ -36,9 +38,9 @@ struct GenArgs {
     int32_t n_mels;
     int32_t n_fft;
     int32_t n_bins;
-    int32_t kpad;              // n_fft rounded up to a multiple of 4
+    int32_t kpad;              // n_fft rounded up to a multiple of 16
     int32_t n_coltiles;        // ceil(2 n_bins / 16)
-    int32_t lda;               // floats per staged frame row (kpad + 4)
+    int32_t lda;               // floats per (n & 3, frame) row of staged samples
     int32_t ldp;               // floats per power-spectrum row (multiple of 4, + slack for mel over-read)
     int32_t hop;
     int32_t pad;
@@ -54,8 +56,8 @@ template <int PW>
 __global__ __launch_bounds__(256) void k_melspec_generic(const GenArgs a) {
     using namespace k2048;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* A = lds;                       // 16 x lda
-    float* P = lds + 16 * a.lda;          // 16 x ldp
+    float* A = lds;                       // 64 x lda
+    float* P = lds + 64 * a.lda;          // 16 x ldp
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_tiles = a.hdr->n_tiles;
@@ -93,9 +95,8 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const GenArgs a) {
         const bool pcm16 = a.pcm16 != 0;
         for (int fi = 0; fi < 4; ++fi) {
             const int f = 4 * wave + fi;
-            float* rowp = A + f * a.lda;
             const int start = (ti.f0 + f) * a.hop - a.pad;
-            for (int n = lane; n < a.lda; n += 64) {
+            for (int n = lane; n < a.kpad; n += 64) {
                 float v = 0.0f;
                 if (f < nvalid && n < a.n_fft) {
                     const int idx = start + n;
@@ -106,30 +107,38 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const GenArgs a) {
                     }
                     v *= a.window[n];
                 }
-                rowp[n] = v;
+                A[((n & 3) * 16 + f) * a.lda + (n >> 2)] = v;
             }
         }
         __syncthreads();
 
         // ---- DFT on the matrix cores, power, -> P ------------------------------------------------
-        const float* arow = A + (lane & 15) * a.lda + (lane >> 4);
-        const int ksteps = a.kpad >> 2;
+        // lane supplies A[frame = lane & 15][k = 4 s + (lane >> 4)]: four steps per 16-byte read
+        const float4* arow = reinterpret_cast<const float4*>(A + ((lane >> 4) * 16 + (lane & 15)) * a.lda);
+        const int ks4 = a.kpad >> 4;
         for (int ct = wave; ct < a.n_coltiles; ct += 4) {
-            const float* frag = a.dfrag + (size_t)ct * ksteps * 64 + lane;
+            const float4* frag = reinterpret_cast<const float4*>(a.dfrag) + (size_t)ct * ks4 * 64 + lane;
             gen_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
             int s = 0;
-            for (; s + 8 <= ksteps; s += 8) {
-                float av[8], bv[8];
+            for (; s + 4 <= ks4; s += 4) {
+                float4 av[4], bv[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { av[j] = arow[4 * (s + j)]; bv[j] = frag[(size_t)(s + j) * 64]; }
+                for (int j = 0; j < 4; ++j) { av[j] = arow[s + j]; bv[j] = frag[(size_t)(s + j) * 64]; }
 #pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j + 1], bv[j + 1], acc1, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
                 }
             }
-            for (; s < ksteps; ++s)
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * s], frag[(size_t)s * 64], acc0, 0, 0, 0);
+            for (; s < ks4; ++s) {
+                const float4 av = arow[s], bv = frag[(size_t)s * 64];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
+            }
             // acc[i]: frame 4 (lane >> 4) + i, column 16 ct + (lane & 15); even column = Re, odd = Im
             const int col = 16 * ct + (lane & 15);
             const int bin = col >> 1;

@@ -602,11 +602,11 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         // Dense DFT matrix [n_fft x 2 n_bins], columns interleaved (cos, -sin), in the B-fragment
         // order of v_mfma_f32_16x16x4_f32: lane l supplies B[k = l >> 4][j = l & 15].
         const int N = r.c.n_fft;
-        p->g_kpad = (N + 3) / 4 * 4;
-        p->g_lda = p->g_kpad + 4;
+        p->g_kpad = (N + 15) / 16 * 16;
+        p->g_lda = 4 * ((p->g_kpad / 16) | 1);      // an odd number of 16-byte quads per row
         p->g_ldp = (std::max(r.n_bins, p->sm.max_read + 1) + 3) / 4 * 4;
         p->g_coltiles = (2 * r.n_bins + 15) / 16;
-        p->g_lds_bytes = sizeof(float) * 16 * ((size_t)p->g_lda + p->g_ldp);
+        p->g_lds_bytes = sizeof(float) * (64 * (size_t)p->g_lda + 16 * (size_t)p->g_ldp);
         if (p->g_lds_bytes > (size_t)k2048::LDS_LIMIT) {
             delete p;
             return fail(MFCC_E_UNSUPPORTED, "n_fft too large for the generic (dense DFT) kernel; "
@@ -620,7 +620,9 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
                     const int n = 4 * s + (l >> 4), col = 16 * ct + (l & 15), bin = col >> 1;
                     if (n >= N || bin >= r.n_bins) continue;
                     const double ang = 2.0 * PI * (double)(((int64_t)n * bin) % N) / (double)N;
-                    dfrag[((size_t)ct * ksteps + s) * 64 + l] = (float)((col & 1) ? -std::sin(ang) : std::cos(ang));
+                    // four consecutive steps of a lane are adjacent: one 16-byte load
+                    dfrag[(((size_t)ct * (ksteps / 4) + s / 4) * 64 + l) * 4 + (s & 3)] =
+                        (float)((col & 1) ? -std::sin(ang) : std::cos(ang));
                 }
     }
     std::vector<MelPass> passes(p->sm.n_pass);
