@@ -52,17 +52,22 @@ struct GenArgs {
 
 typedef float gen_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int PW>
-__global__ __launch_bounds__(256) void k_melspec_generic(const GenArgs a) {
+// NT: 16-frame tiles per workgroup pass (4 NT wavefronts).  Every fragment of the DFT matrix a
+// wavefront fetches is used for all NT tiles, so the matrix traffic per frame falls by NT.
+template <int PW, int NT>
+__global__ __launch_bounds__(256 * NT) void k_melspec_generic(const GenArgs a) {
     using namespace k2048;
+    constexpr int THREADS = 256 * NT, WAVES = 4 * NT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* A = lds;                       // 64 x lda
-    float* P = lds + 64 * a.lda;          // 16 x ldp
+    float* A = lds;                            // NT x 64 x lda
+    float* P = lds + NT * 64 * a.lda;          // NT x 16 x ldp
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tl = wave >> 2, wq = wave & 3;   // this wavefront stages / finishes frames 4 wq .. 4 wq + 3 of tile tl
     const int n_tiles = a.hdr->n_tiles;
-    const int per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
-    const int tile_end = min(n_tiles, (int)(blockIdx.x + 1) * per_wg);
+    const int n_super = (n_tiles + NT - 1) / NT;
+    const int per_wg = (n_super + gridDim.x - 1) / gridDim.x;
+    const int super_end = min(n_super, (int)(blockIdx.x + 1) * per_wg);
 
     int mel_st[MAX_MEL_PASS], mel_fi[MAX_MEL_PASS], mel_rounds[MAX_MEL_PASS], mel_roff[MAX_MEL_PASS];
 #pragma unroll
@@ -76,25 +81,30 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const GenArgs a) {
         }
     }
     // zero the power rows once: the slack past n_bins is read (with zero weights) by the mel stage
-    for (int i = threadIdx.x; i < 16 * a.ldp; i += 256) P[i] = 0.0f;
+    for (int i = threadIdx.x; i < NT * 16 * a.ldp; i += THREADS) P[i] = 0.0f;
 
     float runmax = 0.0f;
     int cur_grp = -1;
+    float* At = A + tl * 64 * a.lda;
+    float* Pt = P + tl * 16 * a.ldp;
 
-    for (int tile = blockIdx.x * per_wg; tile < tile_end; ++tile) {
-        const Tile ti = a.tiles[tile];
-        const int nvalid = min(TILE_FRAMES, ti.F - ti.f0);
-        if (ti.grp != cur_grp) {
+    for (int sup = blockIdx.x * per_wg; sup < super_end; ++sup) {
+        const int tile = sup * NT + tl;
+        const bool have = tile < n_tiles;
+        Tile ti = {};
+        if (have) ti = a.tiles[tile];
+        const int nvalid = have ? min(TILE_FRAMES, ti.F - ti.f0) : 0;
+        if (have && ti.grp != cur_grp) {
             flush_max(runmax, cur_grp, a.gmax, lane);
             cur_grp = ti.grp;
             runmax = 0.0f;
         }
-        __syncthreads();   // previous tile's mel stage is done with P, its DFT with A
+        __syncthreads();   // the previous pass's mel stage is done with P, its DFT with A
 
         // ---- stage: pad + frame + window ------------------------------------------------------
         const bool pcm16 = a.pcm16 != 0;
         for (int fi = 0; fi < 4; ++fi) {
-            const int f = 4 * wave + fi;
+            const int f = 4 * wq + fi;
             const int start = (ti.f0 + f) * a.hop - a.pad;
             for (int n = lane; n < a.kpad; n += 64) {
                 float v = 0.0f;
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const GenArgs a) {
                     }
                     v *= a.window[n];
                 }
-                A[((n & 3) * 16 + f) * a.lda + (n >> 2)] = v;
+                At[((n & 3) * 16 + f) * a.lda + (n >> 2)] = v;
             }
         }
         __syncthreads();
@@ -115,49 +125,69 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const GenArgs a) {
         // ---- DFT on the matrix cores, power, -> P ------------------------------------------------
         // lane supplies A[frame = lane & 15][k = 4 s + (lane >> 4)]: four steps per 16-byte read
         const float4* arow = reinterpret_cast<const float4*>(A + ((lane >> 4) * 16 + (lane & 15)) * a.lda);
+        const int tile_q = 16 * a.lda;        // float4 units between the tiles' staged samples
         const int ks4 = a.kpad >> 4;
-        for (int ct = wave; ct < a.n_coltiles; ct += 4) {
+        for (int ct = wave; ct < a.n_coltiles; ct += WAVES) {
             const float4* frag = reinterpret_cast<const float4*>(a.dfrag) + (size_t)ct * ks4 * 64 + lane;
-            gen_f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            gen_f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { acc0[t] = (gen_f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc1[t] = acc0[t]; }
             int s = 0;
-            for (; s + 4 <= ks4; s += 4) {
-                float4 av[4], bv[4];
+            for (; s + 2 <= ks4; s += 2) {
+                float4 av[2][NT], bv[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { av[j] = arow[s + j]; bv[j] = frag[(size_t)(s + j) * 64]; }
+                for (int j = 0; j < 2; ++j) {
+                    bv[j] = frag[(size_t)(s + j) * 64];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc1, 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) av[j][t] = arow[t * tile_q + s + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t].x, bv[j].x, acc0[t], 0, 0, 0);
+                        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t].y, bv[j].y, acc1[t], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t].z, bv[j].z, acc0[t], 0, 0, 0);
+                        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t].w, bv[j].w, acc1[t], 0, 0, 0);
+                    }
                 }
             }
             for (; s < ks4; ++s) {
-                const float4 av = arow[s], bv = frag[(size_t)s * 64];
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
+                const float4 bv = frag[(size_t)s * 64];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 av = arow[t * tile_q + s];
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1[t], 0, 0, 0);
+                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1[t], 0, 0, 0);
+                }
             }
             // acc[i]: frame 4 (lane >> 4) + i, column 16 ct + (lane & 15); even column = Re, odd = Im
             const int col = 16 * ct + (lane & 15);
             const int bin = col >> 1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float c = acc0[i] + acc1[i];
-                float v = c * c;
-                v += quad_swap1(v);
-                if (!(lane & 1) && bin < a.n_bins)
-                    P[(4 * (lane >> 4) + i) * a.ldp + bin] = apply_power<PW>(v, a.pw_mode, a.half_power);
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float c = acc0[t][i] + acc1[t][i];
+                    float v = c * c;
+                    v += quad_swap1(v);
+                    if (!(lane & 1) && bin < a.n_bins)
+                        P[(t * 16 + 4 * (lane >> 4) + i) * a.ldp + bin] = apply_power<PW>(v, a.pw_mode, a.half_power);
+                }
             }
         }
         __syncthreads();
 
         // ---- per frame: optional spectrogram tap, sparse mel -----------------------------------
         for (int fi = 0; fi < 4; ++fi) {
-            const int f = 4 * wave + fi;
+            const int f = 4 * wq + fi;
             if (f >= nvalid) break;
-            const float* X = P + f * a.ldp;
+            const float* X = Pt + f * a.ldp;
             const int64_t row = ti.row0 + f;
             if (a.spec_out) {
                 float* so = a.spec_out + row * a.n_bins;

@@ -367,7 +367,7 @@ struct mfcc_plan {
     float* d_lifter = nullptr;
     float* d_dfrag = nullptr;
     // generic (dense DFT) front end geometry
-    int g_kpad = 0, g_lda = 0, g_ldp = 0, g_coltiles = 0;
+    int g_kpad = 0, g_lda = 0, g_ldp = 0, g_coltiles = 0, g_nt = 1;
     size_t g_lds_bytes = 0;
     // optional per-kernel timing (mfcc_plan_set_profiling)
     bool profiling = false;
@@ -442,10 +442,20 @@ int select_variant(mfcc_plan* p) {
     return MFCC_OK;
 }
 
+typedef void (*GenericFn)(const GenArgs);
+GenericFn generic_kernel(const mfcc_plan* p) {
+    const bool pw2 = p->r.c.power == 2.0f;
+    switch (p->g_nt) {
+        case 4: return pw2 ? k_melspec_generic<0, 4> : k_melspec_generic<1, 4>;
+        case 3: return pw2 ? k_melspec_generic<0, 3> : k_melspec_generic<1, 3>;
+        case 2: return pw2 ? k_melspec_generic<0, 2> : k_melspec_generic<1, 2>;
+        default: return pw2 ? k_melspec_generic<0, 1> : k_melspec_generic<1, 1>;
+    }
+}
+
 int setup_generic(mfcc_plan* p) {
-    const void* fn = p->r.c.power == 2.0f ? reinterpret_cast<const void*>(k_melspec_generic<0>)
-                                          : reinterpret_cast<const void*>(k_melspec_generic<1>);
-    hipError_t e2 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->g_lds_bytes);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(generic_kernel(p)),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->g_lds_bytes);
     if (e2 != hipSuccess) return fail(MFCC_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e2));
     return MFCC_OK;
 }
@@ -606,8 +616,11 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         p->g_lda = 4 * ((p->g_kpad / 16) | 1);      // an odd number of 16-byte quads per row
         p->g_ldp = (std::max(r.n_bins, p->sm.max_read + 1) + 3) / 4 * 4;
         p->g_coltiles = (2 * r.n_bins + 15) / 16;
-        p->g_lds_bytes = sizeof(float) * (64 * (size_t)p->g_lda + 16 * (size_t)p->g_ldp);
-        if (p->g_lds_bytes > (size_t)k2048::LDS_LIMIT) {
+        const size_t per_tile = sizeof(float) * (64 * (size_t)p->g_lda + 16 * (size_t)p->g_ldp);
+        p->g_nt = (int)std::min<size_t>(4, (size_t)k2048::LDS_LIMIT / per_tile);   // tiles per workgroup pass
+        if (const char* e = getenv("MFCC_HIP_GENERIC_NT")) p->g_nt = std::min(p->g_nt, std::max(1, atoi(e)));
+        p->g_lds_bytes = per_tile * std::max(1, p->g_nt);
+        if (p->g_nt < 1) {
             delete p;
             return fail(MFCC_E_UNSUPPORTED, "n_fft too large for the generic (dense DFT) kernel; "
                                             "supported: n_fft = 2048, or even n_fft up to about 1600");
@@ -721,13 +734,12 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
         ga.reflect = plan->r.c.pad_mode == MFCC_PAD_REFLECT;
         ga.pw_mode = plan->r.c.power == 2.0f ? 0 : (plan->r.c.power == 1.0f ? 1 : 2);
         ga.half_power = 0.5f * plan->r.c.power;
+        const int nt = plan->g_nt;
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)k2048::LDS_LIMIT / plan->g_lds_bytes));
-        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(L.ub_tiles, (int64_t)plan->n_cu * per_cu));
+        const int64_t n_super = (L.ub_tiles + nt - 1) / nt;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_super, (int64_t)plan->n_cu * per_cu));
         if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
-        if (plan->r.c.power == 2.0f)
-            hipLaunchKernelGGL(k_melspec_generic<0>, dim3(grid), dim3(256), plan->g_lds_bytes, st, ga);
-        else
-            hipLaunchKernelGGL(k_melspec_generic<1>, dim3(grid), dim3(256), plan->g_lds_bytes, st, ga);
+        hipLaunchKernelGGL(generic_kernel(plan), dim3(grid), dim3(256 * nt), plan->g_lds_bytes, st, ga);
         if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[1], st));
         HIP_TRY(hipGetLastError());
         return MFCC_OK;
