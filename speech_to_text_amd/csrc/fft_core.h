@@ -107,6 +107,60 @@ FC_HD void rdft32_split(const float (&zr)[16], const float (&zi)[16], float (&ar
     }
 }
 
+// R-point complex DFT (R = 2, 4, 8), natural order in and out.
+template <int R>
+FC_HD void cfft_small(float (&re)[R], float (&im)[R]) {
+    static_assert(R == 2 || R == 4 || R == 8, "cfft_small: R must be 2, 4 or 8");
+    if (R == 2) {
+        const float ar = re[0] + re[1], ai = im[0] + im[1];
+        re[1] = re[0] - re[1]; im[1] = im[0] - im[1];
+        re[0] = ar; im[0] = ai;
+    } else if (R == 4) {
+        bfly4(re[0], im[0], re[1], im[1], re[2], im[2], re[3], im[3]);
+    } else {
+        // decimation in frequency: a = x[i] + x[i+4] feeds the even bins, (x[i] - x[i+4]) W8^i the odd
+        float ar[4], ai[4], br[4], bi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ar[i] = re[i] + re[i + 4]; ai[i] = im[i] + im[i + 4];
+            br[i] = re[i] - re[i + 4]; bi[i] = im[i] - im[i + 4];
+        }
+        cmul(br[1], bi[1], W16_2r, W16_2i);                        // W8^1
+        { const float t = br[2]; br[2] = bi[2]; bi[2] = -t; }      // W8^2 = -i
+        cmul(br[3], bi[3], W16_6r, W16_6i);                        // W8^3
+        bfly4(ar[0], ai[0], ar[1], ai[1], ar[2], ai[2], ar[3], ai[3]);
+        bfly4(br[0], bi[0], br[1], bi[1], br[2], bi[2], br[3], bi[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            re[2 * k] = ar[k]; im[2 * k] = ai[k];
+            re[2 * k + 1] = br[k]; im[2 * k + 1] = bi[k];
+        }
+    }
+}
+
+// DFT of a real sequence r[0 .. 2R-1], R = 2, 4 or 8, through the R-point transform of the packed
+// sequence z[m] = r[2m] + i r[2m+1].  With A[k] = sum_n r[n] exp(-2 pi i n k / (2R)):
+//   (ar[0], ai[0]) = (sum of r[even n], sum of r[odd n]);
+//   (ar[k], ai[k]) = 2 A[k] for k = 1 .. R-1, k != R/2;   (ar[R/2], ai[R/2]) = A[R/2].
+template <int R>
+FC_HD void rdft_cols(const float* r, float (&ar)[R], float (&ai)[R]) {
+    float zr[R], zi[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) { zr[m] = r[2 * m]; zi[m] = r[2 * m + 1]; }
+    cfft_small<R>(zr, zi);
+    ar[0] = zr[0]; ai[0] = zi[0];
+    ar[R / 2] = zr[R / 2]; ai[R / 2] = -zi[R / 2];               // A[R/2] = conj Z[R/2]
+#pragma unroll
+    for (int k = 1; k < R / 2; ++k) {
+        const float a = zr[k], b = zi[k], c = zr[R - k], d = zi[R - k];
+        const float er = a + c, ei = b - d;                      // 2 E[k]
+        float tr = b + d, ti = c - a;                            // 2 O[k] = -i (Z[k] - conj Z[R-k])
+        cmul(tr, ti, W32r[(16 / R) * k], W32i[(16 / R) * k]);    // W_2R^k
+        ar[k] = er + tr;      ai[k] = ei + ti;
+        ar[R - k] = er - tr;  ai[R - k] = ti - ei;
+    }
+}
+
 FC_HD void rdft32(const float (&r)[32], float (&ar)[16], float (&ai)[16]) {
     float zr[16], zi[16];
 #pragma unroll

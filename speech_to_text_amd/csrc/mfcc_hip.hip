@@ -22,6 +22,7 @@
 #include "fft_core.h"
 #include "front_2048.h"
 #include "front_generic.h"
+#include "front_pow2.h"
 #include "host_tables.h"
 
 namespace {
@@ -366,6 +367,12 @@ struct mfcc_plan {
     float* d_dct_frag = nullptr;
     float* d_lifter = nullptr;
     float* d_dfrag = nullptr;
+    // power-of-two front end (n_fft 512 / 1024): 0, or log2(n_fft)
+    int p2_log2n = 0, p2_waves = 0, p2_quads = 0, p2_rounds = 0;
+    size_t p2_lds_bytes = 0;
+    float2* d_p2_tw1 = nullptr;
+    float4* d_p2_melw = nullptr;
+    uint32_t* d_p2_pairs = nullptr;
     // generic (dense DFT) front end geometry
     int g_kpad = 0, g_lda = 0, g_ldp = 0, g_coltiles = 0, g_nt = 1;
     size_t g_lds_bytes = 0;
@@ -437,6 +444,83 @@ int select_variant(mfcc_plan* p) {
         if (!fn) continue;
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->front_lds_bytes);
+        if (e2 != hipSuccess) return fail(MFCC_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e2));
+    }
+    return MFCC_OK;
+}
+
+typedef void (*Pow2Fn)(const Pow2Args);
+template <int L, int W>
+Pow2Fn pow2_pick(bool pw2, bool pcm16) {
+    if (pw2) return pcm16 ? k_melspec_pow2<L, W, 0, true> : k_melspec_pow2<L, W, 0, false>;
+    return pcm16 ? k_melspec_pow2<L, W, 1, true> : k_melspec_pow2<L, W, 1, false>;
+}
+Pow2Fn pow2_kernel(const mfcc_plan* p, bool pcm16) {
+    const bool pw2 = p->r.c.power == 2.0f;
+    if (p->p2_log2n == 9) return p->p2_waves == 16 ? pow2_pick<9, 16>(pw2, pcm16) : pow2_pick<9, 8>(pw2, pcm16);
+    return p->p2_waves == 16 ? pow2_pick<10, 16>(pw2, pcm16) : pow2_pick<10, 8>(pw2, pcm16);
+}
+
+// Tables of the power-of-two front end.  Returns false when the filterbank does not fit its
+// layout (the dense-DFT kernel takes over).
+template <int L>
+bool build_pow2_tables(mfcc_plan* p, const std::vector<float>& basis, std::vector<float2>& tw1,
+                       std::vector<float4>& melw, std::vector<uint32_t>& pairs) {
+    using G = kp2::Geo<L>;
+    const double PI = 3.14159265358979323846;
+    const int n_mels = p->r.c.n_mels, n_bins = p->r.n_bins;
+    tw1.assign((size_t)std::max(1, G::R - 1) * 64, make_float2(1.0f, 0.0f));
+    for (int k2 = 1; k2 < G::R; ++k2)
+        for (int n1 = 0; n1 < 64; ++n1) {
+            const double ang = -2.0 * PI * (double)(n1 * k2) / (double)G::N;
+            const double sc = (k2 == G::R / 2) ? 1.0 : 0.5;   // rdft_cols leaves 2 A[k] except at k = R/2
+            tw1[(size_t)(k2 - 1) * 64 + n1] = make_float2((float)(sc * std::cos(ang)), (float)(sc * std::sin(ang)));
+        }
+    // each filter's span, from a 4-aligned first bin
+    std::vector<int> start(n_mels, 0);
+    int quads = 1;
+    for (int f = 0; f < n_mels; ++f) {
+        int lo = -1, hi = -1;
+        for (int k = 0; k < n_bins; ++k)
+            if (basis[(size_t)f * n_bins + k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
+        if (lo < 0) continue;
+        start[f] = lo & ~3;
+        quads = std::max(quads, (hi - start[f]) / 4 + 1);
+    }
+    for (int f = 0; f < n_mels; ++f)
+        if (start[f] + 4 * quads > G::row_cap()) return false;
+    const int cols = n_mels + 1;
+    melw.assign((size_t)quads * cols, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (int f = 0; f < n_mels; ++f)
+        for (int i = 0; i < quads; ++i) {
+            float w[4];
+            for (int c = 0; c < 4; ++c) {
+                const int k = start[f] + 4 * i + c;
+                w[c] = k < n_bins ? basis[(size_t)f * n_bins + k] : 0.0f;
+            }
+            melw[(size_t)i * cols + f] = make_float4(w[0], w[1], w[2], w[3]);
+        }
+    const int n_pairs = G::T * n_mels;
+    const int rounds = (n_pairs + 63) / 64;
+    pairs.assign((size_t)rounds * 64, (uint32_t)n_mels << 16);
+    for (int j = 0; j < n_pairs; ++j) {
+        const int t = j / n_mels, f = j % n_mels;
+        pairs[j] = (uint32_t)(kp2::p_base<L>(t) + start[f]) | ((uint32_t)f << 16);
+    }
+    p->p2_quads = quads;
+    p->p2_rounds = rounds;
+    p->p2_waves = 0;
+    for (int w : {16, 8})
+        if (kp2::lds_bytes(G::REGION, w, n_mels, quads, rounds) <= (size_t)k2048::LDS_LIMIT) { p->p2_waves = w; break; }
+    if (!p->p2_waves) return false;
+    p->p2_lds_bytes = kp2::lds_bytes(G::REGION, p->p2_waves, n_mels, quads, rounds);
+    return true;
+}
+
+int setup_pow2(mfcc_plan* p) {
+    for (bool pcm16 : {false, true}) {
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(pow2_kernel(p, pcm16)),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->p2_lds_bytes);
         if (e2 != hipSuccess) return fail(MFCC_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e2));
     }
     return MFCC_OK;
@@ -607,8 +691,16 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         for (size_t i = 0; i < jobs.size(); ++i)
             jobs[i] = make_int2(4 * p->mj.at[i], 4 * (k2048::MCELL_OFF + p->mj.cell[i]) | (p->mj.cont[i] ? 1 : 0));
     }
+    // n_fft 512 / 1024: the in-register FFT kernel (MFCC_HIP_DENSE_DFT=1 keeps the dense-DFT one)
+    std::vector<float2> p2_tw1;
+    std::vector<float4> p2_melw;
+    std::vector<uint32_t> p2_pairs;
+    if (!std::getenv("MFCC_HIP_DENSE_DFT")) {
+        if (r.c.n_fft == 512 && build_pow2_tables<9>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 9;
+        if (r.c.n_fft == 1024 && build_pow2_tables<10>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 10;
+    }
     std::vector<float> dfrag;
-    if (!p->fast2048) {
+    if (!p->fast2048 && !p->p2_log2n) {
         // Dense DFT matrix [n_fft x 2 n_bins], columns interleaved (cos, -sin), in the B-fragment
         // order of v_mfma_f32_16x16x4_f32: lane l supplies B[k = l >> 4][j = l & 15].
         const int N = r.c.n_fft;
@@ -677,7 +769,10 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
     if (rc == MFCC_OK) rc = upload(frag, &p->d_dct_frag);
     if (rc == MFCC_OK) rc = upload(lifter, &p->d_lifter);
     if (rc == MFCC_OK) rc = upload(dfrag, &p->d_dfrag);
-    if (rc == MFCC_OK) rc = p->fast2048 ? select_variant(p) : setup_generic(p);
+    if (rc == MFCC_OK && p->p2_log2n) rc = upload(p2_tw1, &p->d_p2_tw1);
+    if (rc == MFCC_OK && p->p2_log2n) rc = upload(p2_melw, &p->d_p2_melw);
+    if (rc == MFCC_OK && p->p2_log2n) rc = upload(p2_pairs, &p->d_p2_pairs);
+    if (rc == MFCC_OK) rc = p->fast2048 ? select_variant(p) : (p->p2_log2n ? setup_pow2(p) : setup_generic(p));
     if (rc != MFCC_OK) {
         const std::string keep = g_err;
         mfcc_plan_destroy(p);
@@ -695,6 +790,7 @@ void mfcc_plan_destroy(mfcc_plan* p) {
     (void)hipFree(p->d_mel_filt); (void)hipFree(p->d_mel_pass); (void)hipFree(p->d_mel_jobs);
     (void)hipFree(p->d_dct_frag);
     (void)hipFree(p->d_lifter); (void)hipFree(p->d_dfrag);
+    (void)hipFree(p->d_p2_tw1); (void)hipFree(p->d_p2_melw); (void)hipFree(p->d_p2_pairs);
     for (int i = 0; i < 3; ++i) if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
     delete p;
 }
@@ -719,6 +815,27 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     hipLaunchKernelGGL(k_prepare_tiles, dim3(pt_blocks), dim3(256), 0, st, d_sample_offsets,
                        d_frame_offsets, d_group, tile_off, n_utts, tiles);
 
+    if (plan->p2_log2n) {
+        Pow2Args pa;
+        pa.pcm = d_pcm; pa.tiles = tiles; pa.hdr = hdr;
+        pa.window = plan->d_window; pa.tw1 = plan->d_p2_tw1; pa.w64 = plan->d_w64; pa.tw128 = plan->d_tw128;
+        pa.melw = plan->d_p2_melw; pa.mel_pairs = plan->d_p2_pairs;
+        pa.mel_out = mel_out; pa.spec_out = spec_out; pa.gmax = gmax;
+        pa.n_mels = plan->r.c.n_mels; pa.mel_quads = plan->p2_quads; pa.mel_rounds = plan->p2_rounds;
+        pa.hop = plan->r.c.hop_length;
+        pa.pad = plan->r.c.center ? plan->r.c.n_fft / 2 : 0;
+        pa.reflect = plan->r.c.pad_mode == MFCC_PAD_REFLECT;
+        pa.pw_mode = plan->r.c.power == 2.0f ? 0 : (plan->r.c.power == 1.0f ? 1 : 2);
+        pa.half_power = 0.5f * plan->r.c.power;
+        const int passes_per_tile = (1 << plan->p2_log2n) / 128;
+        const int64_t wg_needed = (L.ub_tiles * passes_per_tile + plan->p2_waves - 1) / plan->p2_waves;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(wg_needed, plan->n_cu));
+        if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
+        hipLaunchKernelGGL(pow2_kernel(plan, pcm16), dim3(grid), dim3(plan->p2_waves * 64), plan->p2_lds_bytes, st, pa);
+        if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[1], st));
+        HIP_TRY(hipGetLastError());
+        return MFCC_OK;
+    }
     if (!plan->fast2048) {
         GenArgs ga;
         ga.pcm = d_pcm; ga.pcm16 = pcm16 ? 1 : 0; ga.tiles = tiles; ga.hdr = hdr;

@@ -4,10 +4,38 @@
 #include <cstdlib>
 #include "../../speech_to_text_amd/csrc/fft_core.h"
 
+template <int R>
+static double check_rdft_cols() {
+    const double PI = 3.14159265358979323846;
+    double worst = 0.0;
+    for (int trial = 0; trial < 50; ++trial) {
+        float r[2 * R], ar[R], ai[R]; double rd[2 * R];
+        for (int n = 0; n < 2 * R; ++n) rd[n] = r[n] = (float)rand() / RAND_MAX - 0.5f;
+        fc::rdft_cols<R>(r, ar, ai);
+        double ev = 0, od = 0;
+        for (int n = 0; n < 2 * R; ++n) ((n & 1) ? od : ev) += rd[n];
+        worst = fmax(worst, fabs(ev - ar[0]));
+        worst = fmax(worst, fabs(od - ai[0]));
+        for (int k = 1; k < R; ++k) {
+            double sr = 0, si = 0;
+            for (int n = 0; n < 2 * R; ++n) {
+                sr += rd[n] * cos(2 * PI * n * k / (2 * R)); si -= rd[n] * sin(2 * PI * n * k / (2 * R));
+            }
+            const double sc = (k == R / 2) ? 1.0 : 2.0;
+            worst = fmax(worst, fabs(sc * sr - ar[k]));
+            worst = fmax(worst, fabs(sc * si - ai[k]));
+        }
+    }
+    return worst;
+}
+
 int main() {
     const double PI = 3.14159265358979323846;
     double worst = 0.0;
     srand(7);
+    worst = fmax(worst, check_rdft_cols<2>());
+    worst = fmax(worst, check_rdft_cols<4>());
+    worst = fmax(worst, check_rdft_cols<8>());
     for (int trial = 0; trial < 50; ++trial) {
         float re[16], im[16]; double xr[16], xi[16];
         for (int n = 0; n < 16; ++n) {
