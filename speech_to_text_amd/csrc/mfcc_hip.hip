@@ -985,6 +985,14 @@ int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_
     return MFCC_OK;
 }
 
+const char* mfcc_plan_front_kernel(const mfcc_plan* plan) {
+    if (!plan) return nullptr;
+    if (plan->fast2048) return "fft2048";
+    if (plan->p2_log2n == 9) return "fft512";
+    if (plan->p2_log2n == 10) return "fft1024";
+    return "dense_dft";
+}
+
 int mfcc_execute_spectrogram(const mfcc_plan* plan, const float* d_pcm,
                              const int64_t* d_sample_offsets, const int64_t* d_frame_offsets,
                              int32_t n_utts, int64_t total_frames, float* d_spec_out,

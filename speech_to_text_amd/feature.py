@@ -65,6 +65,11 @@ class MfccPlan:
         _lib.check(_lib.lib().mfcc_plan_last_timings(self._handle, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    @property
+    def front_kernel(self) -> str:
+        """Which front-end kernel the plan runs: 'fft2048', 'fft512', 'fft1024' or 'dense_dft'."""
+        return _lib.lib().mfcc_plan_front_kernel(self._handle).decode("ascii")
+
     # ------------------------------------------------------------------------------------
     def num_frames(self, n_samples: int) -> int:
         F = _lib.lib().mfcc_num_frames(C.byref(self._cfg_c), int(n_samples))

@@ -95,7 +95,7 @@ def test_mfcc_parity(S, kw):
     np.testing.assert_allclose(got, want, rtol=0, atol=DB_TOL)
 
 
-@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160)])
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160), (512, 128), (1024, 256)])
 def test_spectrogram_parity(S, n_fft, hop):
     y = speech_like(30000, seed=4)
     want = np.abs(R.stft(y, n_fft=n_fft, hop_length=hop)) ** 2

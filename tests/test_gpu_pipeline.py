@@ -127,6 +127,8 @@ def test_asr_frontend_with_cmvn(gpu):
     dict(n_fft=2048, hop_length=512, n_mfcc=13),
     dict(n_fft=2048, hop_length=512, n_mfcc=13, pad_mode="reflect"),
     dict(n_fft=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
+    dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
+    dict(n_fft=1024, hop_length=256, n_mfcc=13),
 ])
 def test_int16_pcm_ingest_is_bit_identical(gpu, kw):
     """16-bit PCM in (value / 32768, the waveform torchaudio decodes a LibriSpeech FLAC into for
@@ -149,6 +151,57 @@ def test_int16_pcm_ingest_is_bit_identical(gpu, kw):
     for x, y in zip(a, b):
         assert x.shape == y.shape and np.array_equal(x, y)
     del rng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,name", [
+    (dict(n_fft=2048, hop_length=512), "fft2048"),
+    (dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, sr=16000), "fft512"),
+    (dict(n_fft=1024, hop_length=256), "fft1024"),
+    (dict(n_fft=400, hop_length=160, n_mels=80, sr=16000), "dense_dft"),
+])
+def test_front_kernel_selection(gpu, kw, name):
+    import speech_to_text_amd as S
+
+    plan = S.MfccPlan(S.make_config(n_mfcc=13, **kw))
+    assert plan.front_kernel == name
+    plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
+    dict(n_fft=1024, hop_length=200, n_mels=128, n_mfcc=20, pad_mode="reflect"),
+    dict(n_fft=512, hop_length=512, n_mels=40, n_mfcc=13, center=False, power=1.0),
+])
+def test_fft_and_dense_dft_kernels_agree(gpu, kw, monkeypatch):
+    """The in-register FFT kernel and the dense-DFT kernel are independent implementations of the
+    same transform; on a ragged batch (with edge frames, a partly filled last pass and utterances
+    shorter than a frame) their MFCCs agree to the parity tolerance."""
+    import torch
+
+    import speech_to_text_amd as S
+
+    cfg = S.make_config(**kw)
+    lens = [1, 159, 160, 511, 512, 513, 4000, 16000, 33333, 7]
+    if not kw.get("center", True):
+        lens = [n for n in lens if n >= kw["n_fft"]]
+    ys = [speech_like(n, seed=40 + i) for i, n in enumerate(lens)]
+    so = np.zeros(len(ys) + 1, dtype=np.int64)
+    np.cumsum([len(y) for y in ys], out=so[1:])
+    pcm = torch.from_numpy(np.concatenate(ys)).cuda()
+    outs = {}
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("MFCC_HIP_DENSE_DFT", "1")
+        plan = S.MfccPlan(cfg)
+        assert plan.front_kernel == ("dense_dft" if dense else f"fft{kw['n_fft']}")
+        fo = plan.frame_offsets(so)
+        out = plan.execute(pcm, torch.from_numpy(so).cuda(), torch.from_numpy(fo).cuda(), int(fo[-1]))
+        outs[dense] = out.cpu().numpy()
+        plan.close()
+    assert outs[False].shape == outs[True].shape and outs[False].shape[0] > 0
+    assert np.abs(outs[False] - outs[True]).max() <= 1e-2          # dB, as for the librosa parity
 
 
 def test_packed_sink_int16_ingest_and_device_dataset(gpu, tmp_path):

@@ -1,4 +1,6 @@
-"""Runs the pipeline a few times on a small batch; meant to be run under rocprofv3 --pmc."""
+"""Runs the pipeline a few times on a small batch; meant to be run under rocprofv3 --pmc.
+
+    python tools/prof_front.py [hours] [iterations] [ref|asr512|asr400|fft1024]"""
 import os, sys
 from pathlib import Path
 import torch
@@ -9,7 +11,11 @@ from bench import make_batch
 hours = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 dev = torch.device("cuda", 0)
-cfg = S.MfccConfig.reference_default()
+which = sys.argv[3] if len(sys.argv) > 3 else "ref"
+cfg = {"ref": S.MfccConfig.reference_default(),
+       "asr512": S.make_config(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13),
+       "asr400": S.make_config(sr=16000, n_fft=400, hop_length=160, n_mels=80, n_mfcc=13),
+       "fft1024": S.make_config(sr=16000, n_fft=1024, hop_length=256, n_mels=80, n_mfcc=13)}[which]
 pcm, so = make_batch(hours, 1234, dev)
 plan = S.MfccPlan(cfg, dev)
 fo = plan.frame_offsets(so)
