@@ -17,7 +17,7 @@
 //          16-point DFT in registers -> X[k2 + 2R (4 ka + kb)]; ka >= 8 are mirror images
 //  the special slots are post-processed as 128-point real DFTs -> bins R j, j = 0 .. 64
 //  mel     lane = (frame, filter) pair: a dot product of the filter's span of the frame's power
-//          spectrum (in LDS) with its weights; T n_mels / 64 rounds, coalesced stores
+//          spectrum (in LDS) with its weights; 64 / T filters per round
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -61,9 +61,10 @@ struct Geo {
 };
 static_assert(Geo<9>::REGION == 2048 && Geo<10>::REGION == 2048, "exchange-sized regions expected");
 
-constexpr size_t lds_bytes(int region, int waves, int n_mels, int mel_quads, int mel_rounds) {
-    return sizeof(float) * ((size_t)waves * region + k2048::W64_FLOATS + 4 * (size_t)mel_quads * (n_mels + 1) +
-                            64 * (size_t)mel_rounds);
+// mel_quads: weight quads of all rounds together; fpr: filters per round
+constexpr size_t lds_bytes(int region, int waves, int fpr, int mel_quads, int mel_rounds) {
+    return sizeof(float) * ((size_t)waves * region + k2048::W64_FLOATS + 4 * (size_t)mel_quads * fpr +
+                            2 * 64 * (size_t)mel_rounds + 4 /* unit counter */);
 }
 
 __device__ __noinline__ void stage_edge_rows(float* X, const void* pcm, int64_t soff, bool pcm16, int start, int T,
@@ -91,14 +92,17 @@ struct Pow2Args {
     const float2* tw1;         // (R - 1) x 64: W_N^(n1 k2), scaled for rdft_cols
     const float2* w64;         // 4 x 16
     const float2* tw128;       // 64
-    const float4* melw;        // mel_quads x (n_mels + 1) quads of weights; the last column is zero
-    const uint32_t* mel_pairs; // mel_rounds x 64: float offset of the pair's first quad in the
-                               // wavefront's region | filter << 16 (filter n_mels: idle)
+    const float4* melw;        // mel_quads x (64 / T) quads of weights: round by round, quad by quad,
+                               // one column per filter of the round
+    const uint2* mel_pairs;    // mel_rounds x 64, per lane: .x = float offset of the pair's first
+                               // quad in the wavefront's region | index of its first weight quad
+                               // << 16; .y = output index frame * n_mels + filter (0xffff: idle) |
+                               // quads of the round << 16
     float* mel_out;
     float* spec_out;
     uint32_t* gmax;
     int32_t n_mels;
-    int32_t mel_quads;
+    int32_t mel_quads;         // all rounds together
     int32_t mel_rounds;
     int32_t hop;
     int32_t pad;
@@ -123,13 +127,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
     float2* w64_l = reinterpret_cast<float2*>(tab);
     tab += W64_FLOATS;
     float4* melw_l = reinterpret_cast<float4*>(tab);
-    const int mel_cols = a.n_mels + 1;
-    uint32_t* pairs_l = reinterpret_cast<uint32_t*>(melw_l + a.mel_quads * mel_cols);
+    constexpr int FPR = 64 / T;                     // filters per mel round
+    uint2* pairs_l = reinterpret_cast<uint2*>(melw_l + a.mel_quads * FPR);
+    int* run_ctr = reinterpret_cast<int*>(pairs_l + a.mel_rounds * 64);
 
     for (int i = tid; i < WAVES * REGION; i += THREADS) lds[i] = 0.0f;
     if (tid < 64) w64_l[(tid >> 4) * W64_STRIDE + (tid & 15)] = a.w64[tid];
-    for (int i = tid; i < a.mel_quads * mel_cols; i += THREADS) melw_l[i] = a.melw[i];
+    for (int i = tid; i < a.mel_quads * FPR; i += THREADS) melw_l[i] = a.melw[i];
     for (int i = tid; i < a.mel_rounds * 64; i += THREADS) pairs_l[i] = a.mel_pairs[i];
+    if (tid == 0) *run_ctr = 0;
     __syncthreads();
 
     const int q = lane & 3, slot = lane >> 2;
@@ -174,17 +180,27 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
     float runmax = 0.0f;
     int cur_grp = -1;
     const int n_tiles = a.hdr->n_tiles;
-    // Work unit = T consecutive frames of a tile (R units per 16-frame tile); each wavefront takes
-    // a contiguous range of units, so consecutive passes re-read overlapping samples from cache.
+    // Work unit = T consecutive frames of a tile (R units per 16-frame tile).  Each workgroup owns
+    // a contiguous run of units and its wavefronts take them one at a time from a counter in LDS
+    // (the next one is requested a pass ahead): at any moment the CU works on neighbouring frames,
+    // which share most of their samples, and its wavefronts finish together.
     const int64_t n_units = (int64_t)n_tiles * R;
-    const int64_t n_w = (int64_t)gridDim.x * WAVES;
-    const int64_t per = (n_units + n_w - 1) / n_w;
-    const int64_t u0 = ((int64_t)blockIdx.x * WAVES + wave) * per;
-    const int64_t u1 = min(n_units, u0 + per);
+    const int64_t per = (n_units + gridDim.x - 1) / gridDim.x;
+    const int64_t u0 = (int64_t)blockIdx.x * per;
+    const int count = u0 < n_units ? (int)min(per, n_units - u0) : 0;
+    auto request_unit = [&]() -> int {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(run_ctr, 1);
+        return v;
+    };
     int tix = -2;
     Tile ti = {}, ti_next = {};
 
-    for (int64_t u = u0; u < u1; ++u) {
+    int next_v = 0;
+    for (int cur = __builtin_amdgcn_readfirstlane(request_unit()); cur < count;
+         cur = __builtin_amdgcn_readfirstlane(next_v)) {
+        next_v = request_unit();
+        const int64_t u = u0 + cur;
         const int tidx = (int)(u / R), sub = (int)(u % R);
         if (tidx != tix) {
             ti = (tidx == tix + 1) ? ti_next : load_tile(a.tiles, tidx);
@@ -326,18 +342,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
         }
 
         // ---- sparse mel filterbank: lane = (frame, filter) pair --------------------------------------
+        // Round rd takes the filters rd FPR .. rd FPR + FPR - 1 of all T frames; filters of one round
+        // have similar widths, so each round reads only as many quads as its widest filter.
         if (a.mel_out) {
             float* mo = a.mel_out + row0 * a.n_mels;
             const int n_out = nvalid * a.n_mels;
-            const int nq = a.mel_quads;
             for (int rd = 0; rd < a.mel_rounds; ++rd) {
-                const uint32_t e = pairs_l[rd * 64 + lane];
-                const float4* pp = reinterpret_cast<const float4*>(X + (e & 0xffffu));
-                const float4* wp = melw_l + (e >> 16);
+                const uint2 e = pairs_l[rd * 64 + lane];
+                const int nq = __builtin_amdgcn_readfirstlane(e.y >> 16);
+                const float4* pp = reinterpret_cast<const float4*>(X + (e.x & 0xffffu));
+                const float4* wp = melw_l + (e.x >> 16);
                 float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll 2
                 for (int i = 0; i < nq; ++i) {
-                    const float4 w = wp[i * mel_cols];
+                    const float4 w = wp[i * FPR];
                     const float4 v = pp[i];
                     acc0 = fmaf(w.x, v.x, acc0);
                     acc1 = fmaf(w.y, v.y, acc1);
@@ -345,9 +363,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
                     acc1 = fmaf(w.w, v.w, acc1);
                 }
                 const float acc = acc0 + acc1;
-                const int j = rd * 64 + lane;
-                if (j < n_out) {
-                    mo[j] = acc;
+                const int oi = (int)(e.y & 0xffffu);
+                if (oi < n_out) {
+                    mo[oi] = acc;
                     runmax = fmaxf(runmax, acc);
                 }
             }

@@ -372,7 +372,7 @@ struct mfcc_plan {
     size_t p2_lds_bytes = 0;
     float2* d_p2_tw1 = nullptr;
     float4* d_p2_melw = nullptr;
-    uint32_t* d_p2_pairs = nullptr;
+    uint2* d_p2_pairs = nullptr;
     // generic (dense DFT) front end geometry
     int g_kpad = 0, g_lda = 0, g_ldp = 0, g_coltiles = 0, g_nt = 1;
     size_t g_lds_bytes = 0;
@@ -465,7 +465,7 @@ Pow2Fn pow2_kernel(const mfcc_plan* p, bool pcm16) {
 // layout (the dense-DFT kernel takes over).
 template <int L>
 bool build_pow2_tables(mfcc_plan* p, const std::vector<float>& basis, std::vector<float2>& tw1,
-                       std::vector<float4>& melw, std::vector<uint32_t>& pairs) {
+                       std::vector<float4>& melw, std::vector<uint2>& pairs) {
     using G = kp2::Geo<L>;
     const double PI = 3.14159265358979323846;
     const int n_mels = p->r.c.n_mels, n_bins = p->r.n_bins;
@@ -477,43 +477,54 @@ bool build_pow2_tables(mfcc_plan* p, const std::vector<float>& basis, std::vecto
             tw1[(size_t)(k2 - 1) * 64 + n1] = make_float2((float)(sc * std::cos(ang)), (float)(sc * std::sin(ang)));
         }
     // each filter's span, from a 4-aligned first bin
-    std::vector<int> start(n_mels, 0);
-    int quads = 1;
+    std::vector<int> start(n_mels, 0), fq(n_mels, 1);
     for (int f = 0; f < n_mels; ++f) {
         int lo = -1, hi = -1;
         for (int k = 0; k < n_bins; ++k)
             if (basis[(size_t)f * n_bins + k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
         if (lo < 0) continue;
         start[f] = lo & ~3;
-        quads = std::max(quads, (hi - start[f]) / 4 + 1);
+        fq[f] = (hi - start[f]) / 4 + 1;
     }
+    // round rd: filters rd fpr .. rd fpr + fpr - 1 for all T frames, as many quads as the widest
+    constexpr int fpr = 64 / G::T;
+    const int rounds = (n_mels + fpr - 1) / fpr;
+    std::vector<int> nq(rounds, 1), qoff(rounds + 1, 0);
+    for (int f = 0; f < n_mels; ++f) nq[f / fpr] = std::max(nq[f / fpr], fq[f]);
+    for (int rd = 0; rd < rounds; ++rd) qoff[rd + 1] = qoff[rd] + nq[rd];
     for (int f = 0; f < n_mels; ++f)
-        if (start[f] + 4 * quads > G::row_cap()) return false;
-    const int cols = n_mels + 1;
-    melw.assign((size_t)quads * cols, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-    for (int f = 0; f < n_mels; ++f)
-        for (int i = 0; i < quads; ++i) {
-            float w[4];
-            for (int c = 0; c < 4; ++c) {
-                const int k = start[f] + 4 * i + c;
-                w[c] = k < n_bins ? basis[(size_t)f * n_bins + k] : 0.0f;
+        if (start[f] + 4 * nq[f / fpr] > G::row_cap()) return false;
+    const int quads = qoff[rounds];
+    if ((size_t)quads * fpr > 0xffffu) return false;
+    melw.assign((size_t)quads * fpr, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    pairs.assign((size_t)rounds * 64, make_uint2(0u, 0xffffu));
+    for (int rd = 0; rd < rounds; ++rd)
+        for (int fi = 0; fi < fpr; ++fi) {
+            const int f = rd * fpr + fi;
+            const bool live = f < n_mels;
+            if (live)
+                for (int i = 0; i < nq[rd]; ++i) {
+                    float w[4];
+                    for (int c = 0; c < 4; ++c) {
+                        const int k = start[f] + 4 * i + c;
+                        w[c] = k < n_bins ? basis[(size_t)f * n_bins + k] : 0.0f;
+                    }
+                    melw[(size_t)(qoff[rd] + i) * fpr + fi] = make_float4(w[0], w[1], w[2], w[3]);
+                }
+            for (int t = 0; t < G::T; ++t) {
+                const uint32_t p_off = (uint32_t)(kp2::p_base<L>(t) + (live ? start[f] : 0));
+                const uint32_t w_idx = (uint32_t)(qoff[rd] * fpr + fi);
+                const uint32_t out = live ? (uint32_t)(t * n_mels + f) : 0xffffu;
+                pairs[(size_t)rd * 64 + t * fpr + fi] = make_uint2(p_off | (w_idx << 16), out | ((uint32_t)nq[rd] << 16));
             }
-            melw[(size_t)i * cols + f] = make_float4(w[0], w[1], w[2], w[3]);
         }
-    const int n_pairs = G::T * n_mels;
-    const int rounds = (n_pairs + 63) / 64;
-    pairs.assign((size_t)rounds * 64, (uint32_t)n_mels << 16);
-    for (int j = 0; j < n_pairs; ++j) {
-        const int t = j / n_mels, f = j % n_mels;
-        pairs[j] = (uint32_t)(kp2::p_base<L>(t) + start[f]) | ((uint32_t)f << 16);
-    }
     p->p2_quads = quads;
     p->p2_rounds = rounds;
     p->p2_waves = 0;
     for (int w : {16, 8})
-        if (kp2::lds_bytes(G::REGION, w, n_mels, quads, rounds) <= (size_t)k2048::LDS_LIMIT) { p->p2_waves = w; break; }
+        if (kp2::lds_bytes(G::REGION, w, fpr, quads, rounds) <= (size_t)k2048::LDS_LIMIT) { p->p2_waves = w; break; }
     if (!p->p2_waves) return false;
-    p->p2_lds_bytes = kp2::lds_bytes(G::REGION, p->p2_waves, n_mels, quads, rounds);
+    p->p2_lds_bytes = kp2::lds_bytes(G::REGION, p->p2_waves, fpr, quads, rounds);
     return true;
 }
 
@@ -694,7 +705,7 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
     // n_fft 512 / 1024: the in-register FFT kernel (MFCC_HIP_DENSE_DFT=1 keeps the dense-DFT one)
     std::vector<float2> p2_tw1;
     std::vector<float4> p2_melw;
-    std::vector<uint32_t> p2_pairs;
+    std::vector<uint2> p2_pairs;
     if (!std::getenv("MFCC_HIP_DENSE_DFT")) {
         if (r.c.n_fft == 512 && build_pow2_tables<9>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 9;
         if (r.c.n_fft == 1024 && build_pow2_tables<10>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 10;

@@ -1,11 +1,11 @@
 #!/bin/bash
-# usage: pmc_run.sh <outdir> <hours> -- runs three PMC passes of tools/prof_front.py
+# usage: pmc_run.sh <outdir> <hours> [config] -- runs three PMC passes of tools/prof_front.py
 set -e
 O=$1; H=${2:-1}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/p1 -- python3 $R/tools/prof_front.py $H 2 > $O/p1.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY --output-format csv -d $O/p2 -- python3 $R/tools/prof_front.py $H 2 > $O/p2.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VALU_FMA_F32 SQ_IFETCH --output-format csv -d $O/p3 -- python3 $R/tools/prof_front.py $H 2 > $O/p3.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/p1 -- python3 $R/tools/prof_front.py $H 2 ${3:-ref} > $O/p1.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY --output-format csv -d $O/p2 -- python3 $R/tools/prof_front.py $H 2 ${3:-ref} > $O/p2.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VALU_FMA_F32 SQ_IFETCH --output-format csv -d $O/p3 -- python3 $R/tools/prof_front.py $H 2 ${3:-ref} > $O/p3.log 2>&1
 python3 $R/tools/pmc_summary.py $O k_melspec
