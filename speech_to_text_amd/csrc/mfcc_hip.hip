@@ -192,34 +192,41 @@ __global__ __launch_bounds__(256) void k_db_dct(const DbDctArgs a) {
     }
 }
 
-// The reference's shape (128 mels, at most 16 coefficients, 16-byte aligned rows): persistent
-// wavefronts keep the DCT fragments in registers, have a whole tile's eight 16-byte loads in
-// flight at once and request the next tile's before working on the current one.
-__global__ __launch_bounds__(256) void k_db_dct_128(const DbDctArgs a) {
+// At most 128 mels (a multiple of 4, rows 16-byte aligned) and at most 16 coefficients -- the
+// reference's shape is NQ = 8: persistent wavefronts keep the DCT fragments in registers, have a
+// whole tile's NQ 16-byte loads in flight at once and request the next tile's before working on
+// the current one.  NQ = ceil(n_mels / 16).
+template <int NQ>
+__global__ __launch_bounds__(256) void k_db_dct_small(const DbDctArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_tiles = a.hdr->n_tiles;
     const int n_waves = gridDim.x * 4;
     const int f = lane & 15, kq = lane >> 4;
-    float frag[32];
+    float frag[4 * NQ];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) frag[s] = a.dct_frag[s * 64 + lane];
+    for (int s = 0; s < 4 * NQ; ++s) frag[s] = a.dct_frag[s * 64 + lane];
     float lift[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) lift[i] = (4 * kq + i < a.n_mfcc) ? a.lifter[4 * kq + i] : 0.0f;
+    // mel index of this lane's last quad; past the row's end its DCT weights are zero and the
+    // load is redirected to the row's start
+    const int last_k = 16 * (NQ - 1) + 4 * kq;
+    const int last_off = last_k + 3 < a.n_mels ? last_k : 0;
 
-    auto load_tile = [&](int tile, Tile& ti, float4 (&t)[8]) {
+    auto load_tile = [&](int tile, Tile& ti, float4 (&t)[NQ]) {
         ti = a.tiles[tile];
         const int nvalid = min(TILE_FRAMES, ti.F - ti.f0);
-        const float* mrow = a.mel + (ti.row0 + min(f, nvalid - 1)) * 128 + 4 * kq;
+        const float* mrow = a.mel + (ti.row0 + min(f, nvalid - 1)) * a.n_mels;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4*>(mrow + 16 * j);
+        for (int j = 0; j < NQ - 1; ++j) t[j] = *reinterpret_cast<const float4*>(mrow + 4 * kq + 16 * j);
+        t[NQ - 1] = *reinterpret_cast<const float4*>(mrow + last_off);
     };
 
     int tile = blockIdx.x * 4 + wave;
     if (tile >= n_tiles) return;
     Tile ti, ti_n;
-    float4 t[8], tn[8];
+    float4 t[NQ], tn[NQ];
     load_tile(tile, ti, t);
     for (; tile < n_tiles; tile += n_waves) {
         const bool more = tile + n_waves < n_tiles;
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(256) void k_db_dct_128(const DbDctArgs a) {
         }
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NQ; ++j) {
             const float v[4] = {t[j].x, t[j].y, t[j].z, t[j].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(256) void k_db_dct_128(const DbDctArgs a) {
         if (more) {
             ti = ti_n;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = tn[j];
+            for (int j = 0; j < NQ; ++j) t[j] = tn[j];
         }
     }
 }
@@ -953,9 +960,20 @@ static int execute_impl(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     da.vec_ok = (plan->r.c.n_mels % 4 == 0) && (reinterpret_cast<uintptr_t>(mel) % 16 == 0);
     da.amin = plan->r.c.amin; da.ref_db = plan->ref_db; da.top_db = plan->r.c.top_db;
     const int blocks = (int)((L.ub_tiles + 3) / 4);
-    if (da.vec_ok && da.n_mels == 128 && da.n_mfcc <= 16) {
+    if (da.vec_ok && da.n_mels <= 128 && da.n_mfcc <= 16) {
         const int grid = std::max(1, std::min(blocks, plan->n_cu * 8));
-        hipLaunchKernelGGL(k_db_dct_128, dim3(grid), dim3(256), 0, st, da);
+        void (*fn)(const DbDctArgs) = nullptr;
+        switch ((da.n_mels + 15) / 16) {
+            case 1: fn = k_db_dct_small<1>; break;
+            case 2: fn = k_db_dct_small<2>; break;
+            case 3: fn = k_db_dct_small<3>; break;
+            case 4: fn = k_db_dct_small<4>; break;
+            case 5: fn = k_db_dct_small<5>; break;
+            case 6: fn = k_db_dct_small<6>; break;
+            case 7: fn = k_db_dct_small<7>; break;
+            default: fn = k_db_dct_small<8>; break;
+        }
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, st, da);
     } else {
         hipLaunchKernelGGL(k_db_dct, dim3(blocks), dim3(256), 0, st, da);
     }
