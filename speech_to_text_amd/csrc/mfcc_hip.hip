@@ -374,7 +374,7 @@ struct mfcc_plan {
     float* d_dct_frag = nullptr;
     float* d_lifter = nullptr;
     float* d_dfrag = nullptr;
-    // power-of-two front end (n_fft 512 / 1024): 0, or log2(n_fft)
+    // power-of-two front end (n_fft 256 / 512 / 1024): 0, or log2(n_fft)
     int p2_log2n = 0, p2_waves = 0, p2_quads = 0, p2_rounds = 0;
     size_t p2_lds_bytes = 0;
     float2* d_p2_tw1 = nullptr;
@@ -464,6 +464,7 @@ Pow2Fn pow2_pick(bool pw2, bool pcm16) {
 }
 Pow2Fn pow2_kernel(const mfcc_plan* p, bool pcm16) {
     const bool pw2 = p->r.c.power == 2.0f;
+    if (p->p2_log2n == 8) return p->p2_waves == 16 ? pow2_pick<8, 16>(pw2, pcm16) : pow2_pick<8, 8>(pw2, pcm16);
     if (p->p2_log2n == 9) return p->p2_waves == 16 ? pow2_pick<9, 16>(pw2, pcm16) : pow2_pick<9, 8>(pw2, pcm16);
     return p->p2_waves == 16 ? pow2_pick<10, 16>(pw2, pcm16) : pow2_pick<10, 8>(pw2, pcm16);
 }
@@ -709,11 +710,12 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         for (size_t i = 0; i < jobs.size(); ++i)
             jobs[i] = make_int2(4 * p->mj.at[i], 4 * (k2048::MCELL_OFF + p->mj.cell[i]) | (p->mj.cont[i] ? 1 : 0));
     }
-    // n_fft 512 / 1024: the in-register FFT kernel (MFCC_HIP_DENSE_DFT=1 keeps the dense-DFT one)
+    // n_fft 256 / 512 / 1024: the in-register FFT kernel (MFCC_HIP_DENSE_DFT=1 keeps the dense-DFT one)
     std::vector<float2> p2_tw1;
     std::vector<float4> p2_melw;
     std::vector<uint2> p2_pairs;
     if (!std::getenv("MFCC_HIP_DENSE_DFT")) {
+        if (r.c.n_fft == 256 && build_pow2_tables<8>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 8;
         if (r.c.n_fft == 512 && build_pow2_tables<9>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 9;
         if (r.c.n_fft == 1024 && build_pow2_tables<10>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 10;
     }
@@ -1017,6 +1019,7 @@ int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_
 const char* mfcc_plan_front_kernel(const mfcc_plan* plan) {
     if (!plan) return nullptr;
     if (plan->fast2048) return "fft2048";
+    if (plan->p2_log2n == 8) return "fft256";
     if (plan->p2_log2n == 9) return "fft512";
     if (plan->p2_log2n == 10) return "fft1024";
     return "dense_dft";

@@ -85,6 +85,7 @@ def test_melspectrogram_parity(S, kw):
     dict(n_fft=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
     dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
     dict(n_fft=1024, hop_length=256, n_mfcc=13, n_mels=80),
+    dict(n_fft=256, hop_length=80, n_mfcc=13, n_mels=40, sr=8000),
 ])
 def test_mfcc_parity(S, kw):
     y = speech_like(52001, seed=5)
@@ -95,7 +96,7 @@ def test_mfcc_parity(S, kw):
     np.testing.assert_allclose(got, want, rtol=0, atol=DB_TOL)
 
 
-@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160), (512, 128), (1024, 256)])
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160), (512, 128), (1024, 256), (256, 64)])
 def test_spectrogram_parity(S, n_fft, hop):
     y = speech_like(30000, seed=4)
     want = np.abs(R.stft(y, n_fft=n_fft, hop_length=hop)) ** 2

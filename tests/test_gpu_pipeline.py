@@ -129,6 +129,7 @@ def test_asr_frontend_with_cmvn(gpu):
     dict(n_fft=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
     dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
     dict(n_fft=1024, hop_length=256, n_mfcc=13),
+    dict(n_fft=256, hop_length=80, n_mels=40, n_mfcc=13, sr=8000),
 ])
 def test_int16_pcm_ingest_is_bit_identical(gpu, kw):
     """16-bit PCM in (value / 32768, the waveform torchaudio decodes a LibriSpeech FLAC into for
@@ -158,6 +159,7 @@ def test_int16_pcm_ingest_is_bit_identical(gpu, kw):
     (dict(n_fft=2048, hop_length=512), "fft2048"),
     (dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, sr=16000), "fft512"),
     (dict(n_fft=1024, hop_length=256), "fft1024"),
+    (dict(n_fft=256, hop_length=80, n_mels=40, sr=8000), "fft256"),
     (dict(n_fft=400, hop_length=160, n_mels=80, sr=16000), "dense_dft"),
 ])
 def test_front_kernel_selection(gpu, kw, name):
@@ -173,6 +175,8 @@ def test_front_kernel_selection(gpu, kw, name):
     dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
     dict(n_fft=1024, hop_length=200, n_mels=128, n_mfcc=20, pad_mode="reflect"),
     dict(n_fft=512, hop_length=512, n_mels=40, n_mfcc=13, center=False, power=1.0),
+    dict(n_fft=256, hop_length=80, n_mels=40, n_mfcc=13, sr=8000),
+    dict(n_fft=256, win_length=200, hop_length=64, n_mels=128, n_mfcc=20, sr=8000, pad_mode="reflect"),
 ])
 def test_fft_and_dense_dft_kernels_agree(gpu, kw, monkeypatch):
     """The in-register FFT kernel and the dense-DFT kernel are independent implementations of the

@@ -6,8 +6,9 @@
 config 3  1000 h: the 10 h resident batch looped 100 times, HIP-event kernel times (no new
           audio is generated per pass; a 1000 h corpus does not fit one GPU, each rank would
           stream its share through resident batches of this size)
-config 4  ASR front end: sr 16000, hop 160, 80 mels, 13 MFCC with n_fft = 400 and with
-          n_fft = 512 / win_length = 400, + global CMVN (accumulate, apply)
+config 4  ASR front end: sr 16000, hop 160, 80 mels, 13 MFCC with n_fft = 400 (dense-DFT kernel)
+          and with n_fft = 512 / win_length = 400 (the 400-sample window zero-padded to a
+          512-point FFT; in-register FFT kernel), + global CMVN (accumulate, apply)
 config 5  long utterances U(30, 60) s, one of them silent but for a click
 
 Each entry: audio-hours/s from wall time over whole steps (synchronised), per-kernel HIP-event
@@ -73,8 +74,9 @@ def run(config, pcm, so, steps, warmup, with_cmvn=False):
         "algorithmic_bytes_front": 4.0 * float(so[-1]) + 4.0 * config.n_mels * F,
     }
     res["front_GBps"] = res["algorithmic_bytes_front"] / (res["front_kernel_ms"] * 1e-3) / 1e9
-    if config.n_fft != 2048:
-        kpad = (config.n_fft + 3) // 4 * 4
+    res["front_kernel"] = plan.front_kernel
+    if plan.front_kernel == "dense_dft":
+        kpad = (config.n_fft + 15) // 16 * 16
         coltiles = (2 * n_bins + 15) // 16
         flops = 2.0 * 16 * kpad * 16 * coltiles * ((F + 15) // 16)     # MFMA work incl. padding
         res["dense_dft_mfma_tflops"] = flops / (res["front_kernel_ms"] * 1e-3) / 1e12
