@@ -8,7 +8,9 @@ half their size on gfx950), TCC_EA0_WRREQ counts 32- or 64-byte write requests."
 import csv, glob, json, sys, collections, shutil
 from pathlib import Path
 
-src = Path(sys.argv[1]); tag = sys.argv[2]; out = Path(__file__).resolve().parent.parent / "profiles"
+src = Path(sys.argv[1]); tag = sys.argv[2]
+command = sys.argv[3] if len(sys.argv) > 3 else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+out = Path(__file__).resolve().parent.parent / "profiles"
 out.mkdir(exist_ok=True)
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob(str(src / "**/*counter_collection.csv"), recursive=True):
@@ -37,7 +39,7 @@ if log.exists():
     for line in log.read_text().splitlines():
         if line.startswith("{") and '"metric"' in line:
             bench_line = json.loads(line)
-json.dump({"command": "rocprofv3 ... -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (one run per counter set)",
+json.dump({"command": f"rocprofv3 ... -- {command} (one run per counter set)",
            "kernels": summary, "kernel_stats": rows, "bench_line_under_profiler": bench_line},
           open(out / f"{tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: {"hbm_bytes": v["hbm_bytes"]} for k, v in summary.items()}, indent=1))
