@@ -1,0 +1,268 @@
+// 400-point front end for gfx950 (the 25 ms window of 16 kHz speech front ends taken as the
+// transform length, e.g. n_fft = 400, hop 160, 80 mels): one wavefront per four consecutive
+// frames, no barriers in the frame loop.
+//
+//   pad / frame / window -> 400-point real DFT (25 x 16) -> |X|^power -> sparse mel filterbank
+//
+// Same role as front_2048.h (the stft + abs**power + mel einsum part of librosa.feature.mfcc,
+// /root/reference/src/preprocess.py:134) for n_fft = 400.
+//
+// Frame x[n], n = 16 a + b (a < 25, b < 16); bin k = c + 25 d (c < 25, d < 16):
+//     W_400^(n k) = W_25^(a c) W_400^(b c) W_16^(b d)
+//  step 1  lane (t = lane>>4, b = lane&15) holds the 25 samples a = 0..24 of frame t and computes
+//          the real 25-point DFT over a for c = 0..12 directly from the even / odd parts
+//          x[a] +- x[25-a] (288 fused multiply-adds with literal constants)
+//  twiddle Z[b][c] = Y[b][c] W_400^(b c)
+//  exchange through LDS: column (t, c) = 16 complex, columns 36 floats apart (conflict-free
+//          16-byte reads)
+//  step 2  lane t 13 + c (52 of 64 lanes) reads its column and does the 16-point DFT over b in
+//          registers -> X[c + 25 d]; d >= 8 are the mirror images 400 - k of the columns c > 12
+//  mel     as in front_pow2.h: lane = (frame, filter) pair, 16 filters per round
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "front_pow2.h"
+
+namespace k400 {
+constexpr int N = 400, NB = 201, T = 4, NA = 25, NBL = 16, NC = 13;
+constexpr int COL = 36;                 // floats per exchange column: 16 complex + 4 floats of padding
+constexpr int REGION = k2048::XCH_FLOATS;
+constexpr int P_STRIDE = 272;           // frame t's power spectrum starts at float 272 t: the bases
+                                        // are 16 floats apart modulo 64, so the 52 lanes of a store
+                                        // (13 consecutive bins per frame) hit 52 different banks
+constexpr int TW_FLOATS = 12 * 16 * 2;  // W_400^(b c), c = 1..12
+static_assert(T * NC * COL <= REGION && T * P_STRIDE <= REGION, "wavefront region too small");
+__host__ __device__ constexpr int p_base(int t) { return P_STRIDE * t; }
+
+constexpr size_t lds_bytes(int waves, int mel_quads, int mel_rounds) {
+    return sizeof(float) * ((size_t)waves * REGION + TW_FLOATS + 4 * (size_t)mel_quads * (64 / T) +
+                            2 * 64 * (size_t)mel_rounds + 4 /* unit counter */);
+}
+
+// cos, sin of 2 pi j / 25
+constexpr float C25[25] = {
+    1.0f, 0.96858316112863108f, 0.87630668004386358f, 0.72896862742141155f, 0.53582679497899655f,
+    0.30901699437494745f, 0.062790519529313527f, -0.1873813145857246f, -0.42577929156507272f,
+    -0.63742398974868975f, -0.80901699437494734f, -0.92977648588825135f, -0.99211470131447776f,
+    -0.99211470131447788f, -0.92977648588825146f, -0.80901699437494778f, -0.63742398974868952f,
+    -0.42577929156507216f, -0.18738131458572463f, 0.062790519529312833f, 0.30901699437494723f,
+    0.53582679497899677f, 0.72896862742141122f, 0.87630668004386314f, 0.96858316112863097f};
+constexpr float S25[25] = {
+    0.0f, 0.24868988716485479f, 0.48175367410171532f, 0.68454710592868862f, 0.84432792550201508f,
+    0.95105651629515353f, 0.99802672842827156f, 0.98228725072868872f, 0.90482705246601947f,
+    0.77051324277578925f, 0.58778525229247325f, 0.36812455268467814f, 0.12533323356430454f,
+    -0.12533323356430429f, -0.36812455268467792f, -0.58778525229247269f, -0.77051324277578936f,
+    -0.9048270524660198f, -0.98228725072868872f, -0.99802672842827156f, -0.95105651629515364f,
+    -0.84432792550201496f, -0.68454710592868895f, -0.4817536741017161f, -0.24868988716485535f};
+
+// Real 25-point DFT, bins 0..12: Y[c] = sum_a x[a] exp(-2 pi i a c / 25).
+__host__ __device__ __forceinline__ void rdft25(const float (&x)[25], float (&yr)[13], float (&yi)[13]) {
+    float e[13], o[13];
+    e[0] = x[0]; o[0] = 0.0f;
+#pragma unroll
+    for (int a = 1; a <= 12; ++a) { e[a] = x[a] + x[25 - a]; o[a] = x[a] - x[25 - a]; }
+    float s = e[0];
+#pragma unroll
+    for (int a = 1; a <= 12; ++a) s += e[a];
+    yr[0] = s; yi[0] = 0.0f;
+#pragma unroll
+    for (int c = 1; c <= 12; ++c) {
+        float re = e[0], im = 0.0f;
+#pragma unroll
+        for (int a = 1; a <= 12; ++a) {
+            re = fmaf(e[a], C25[(a * c) % 25], re);
+            im = fmaf(o[a], -S25[(a * c) % 25], im);
+        }
+        yr[c] = re; yi[c] = im;
+    }
+}
+}  // namespace k400
+
+// Pow2Args with tw1 = W_400^(b c) as [c - 1][b] (12 x 16); w64 and tw128 are unused.
+template <int WAVES, int PW, bool PCM16>
+__global__ __launch_bounds__(WAVES * 64) void k_melspec_400(const Pow2Args a) {
+    using namespace k2048;
+    using namespace k400;
+    constexpr int THREADS = WAVES * 64;
+    constexpr int FPR = 64 / T;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* X = lds + wave * REGION;
+    float2* X2 = reinterpret_cast<float2*>(X);
+    float* tab = lds + WAVES * REGION;
+    float2* tw_l = reinterpret_cast<float2*>(tab);
+    tab += TW_FLOATS;
+    float4* melw_l = reinterpret_cast<float4*>(tab);
+    uint2* pairs_l = reinterpret_cast<uint2*>(melw_l + a.mel_quads * FPR);
+    int* run_ctr = reinterpret_cast<int*>(pairs_l + a.mel_rounds * 64);
+
+    for (int i = tid; i < WAVES * REGION; i += THREADS) lds[i] = 0.0f;
+    for (int i = tid; i < TW_FLOATS / 2; i += THREADS) tw_l[i] = a.tw1[i];
+    for (int i = tid; i < a.mel_quads * FPR; i += THREADS) melw_l[i] = a.melw[i];
+    for (int i = tid; i < a.mel_rounds * 64; i += THREADS) pairs_l[i] = a.mel_pairs[i];
+    if (tid == 0) *run_ctr = 0;
+    __syncthreads();
+
+    const int b = lane & 15, tf = lane >> 4;        // step 1: residue and frame of this lane
+    const int col = min(lane, T * NC - 1);          // step 2: column t2 * 13 + c2 (lanes >= 52 idle)
+    const int t2 = col / NC, c2 = col - t2 * NC;
+    const bool active2 = lane < T * NC;
+    float win[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) win[i] = a.window[16 * i + b];
+    const int xw = (tf * NC * COL) / 2 + b;         // complex index of Z[b][0] of frame tf
+    const float* xr = X + col * COL;
+    const int pb = p_base(t2);
+
+    float runmax = 0.0f;
+    int cur_grp = -1;
+    const int n_tiles = a.hdr->n_tiles;
+    // Work unit = 4 consecutive frames of a tile; the workgroup's wavefronts take the units of its
+    // contiguous run one at a time from a counter in LDS (see front_pow2.h).
+    const int64_t n_units = (int64_t)n_tiles * (TILE_FRAMES / T);
+    const int64_t per = (n_units + gridDim.x - 1) / gridDim.x;
+    const int64_t u0 = (int64_t)blockIdx.x * per;
+    const int count = u0 < n_units ? (int)min(per, n_units - u0) : 0;
+    auto request_unit = [&]() -> int {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(run_ctr, 1);
+        return v;
+    };
+    int tix = -2;
+    Tile ti = {}, ti_next = {};
+
+    int next_v = 0;
+    for (int cur = __builtin_amdgcn_readfirstlane(request_unit()); cur < count;
+         cur = __builtin_amdgcn_readfirstlane(next_v)) {
+        next_v = request_unit();
+        const int64_t u = u0 + cur;
+        const int tidx = (int)(u >> 2), sub = (int)(u & 3);
+        if (tidx != tix) {
+            ti = (tidx == tix + 1) ? ti_next : load_tile(a.tiles, tidx);
+            tix = tidx;
+            ti_next = load_tile(a.tiles, min(tix + 1, n_tiles - 1));
+        }
+        const Tile tc = ti;
+        const int fb = tc.f0 + sub * T;
+        const int nvalid = min(T, tc.F - fb);
+        if (nvalid <= 0) continue;
+        if (tc.grp != cur_grp) {
+            flush_max(runmax, cur_grp, a.gmax, lane);
+            cur_grp = tc.grp;
+            runmax = 0.0f;
+        }
+        const int64_t row0 = tc.row0 + (fb - tc.f0);
+
+        // ---- samples, window ----------------------------------------------------------------------
+        float x[NA];
+        const int first = fb * a.hop - a.pad;                 // start of the pass's first frame
+        const bool all_in = nvalid == T && first >= 0 && first + (T - 1) * a.hop + N <= tc.T;
+        if (all_in) {
+            const int64_t s0 = tc.soff + first + tf * a.hop + b;
+            if (PCM16) {
+                const int16_t* pp = static_cast<const int16_t*>(a.pcm) + s0;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) x[i] = PCM16_SCALE * (float)pp[16 * i];
+            } else {
+                const float* pp = static_cast<const float*>(a.pcm) + s0;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) x[i] = pp[16 * i];
+            }
+        } else {
+            // a pass with edge frames (overlapping the padding or the utterance's end) or with
+            // fewer than four frames: frame by frame through LDS
+#pragma unroll
+            for (int i = 0; i < NA; ++i) x[i] = 0.0f;
+#pragma unroll 1
+            for (int t = 0; t < nvalid; ++t) {
+                kp2::stage_edge_rows(X, a.pcm, tc.soff, PCM16, first + t * a.hop, tc.T, a.reflect, lane, 7);
+                if (tf == t) {
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) x[i] = X[16 * i + b];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) x[i] *= win[i];
+
+        // ---- step 1: real DFT-25 over a, twiddle, exchange -----------------------------------------
+        {
+            float yr[NC], yi[NC];
+            rdft25(x, yr, yi);
+            float2 tw[NC];
+#pragma unroll
+            for (int c = 1; c < NC; ++c) tw[c] = tw_l[(c - 1) * 16 + b];
+            X2[xw] = make_float2(yr[0], 0.0f);
+#pragma unroll
+            for (int c = 1; c < NC; ++c) {
+                fc::cmul(yr[c], yi[c], tw[c].x, tw[c].y);
+                X2[xw + c * (COL / 2)] = make_float2(yr[c], yi[c]);
+            }
+        }
+
+        // ---- step 2: DFT-16 over b ---------------------------------------------------------------
+        float dr[16], di[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + 4 * j);
+            dr[2 * j] = v.x; di[2 * j] = v.y; dr[2 * j + 1] = v.z; di[2 * j + 1] = v.w;
+        }
+        fc::cfft16(dr, di);
+
+        // ---- power spectra -> LDS (natural bin order per frame) --------------------------------------
+        // bin c2 + 25 d for d < 8; d >= 8 is the mirror image 25 (16 - d) - c2 (for c2 = 0 only
+        // d = 8, bin 200: the others repeat bins 25 d)
+        if (active2) {
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                const float re = dr[fc::cfft16_pos(d)], im = di[fc::cfft16_pos(d)];
+                const float pw = apply_power<PW>(re * re + im * im, a.pw_mode, a.half_power);
+                if (d < 8) X[pb + c2 + 25 * d] = pw;
+                else if (d == 8 || c2 != 0) X[pb + 25 * (16 - d) - c2] = pw;
+            }
+        }
+
+        if (a.spec_out) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if (t < nvalid) {
+                    float* so = a.spec_out + (row0 + t) * NB;
+                    for (int k = lane; k < NB; k += 64) so[k] = X[p_base(t) + k];
+                }
+            }
+        }
+
+        // ---- sparse mel filterbank: lane = (frame, filter) pair (see front_pow2.h) --------------------
+        if (a.mel_out) {
+            float* mo = a.mel_out + row0 * a.n_mels;
+            const int n_out = nvalid * a.n_mels;
+            for (int rd = 0; rd < a.mel_rounds; ++rd) {
+                const uint2 e = pairs_l[rd * 64 + lane];
+                const int nq = __builtin_amdgcn_readfirstlane(e.y >> 16);
+                const float4* pp = reinterpret_cast<const float4*>(X + (e.x & 0xffffu));
+                const float4* wp = melw_l + (e.x >> 16);
+                float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll 2
+                for (int i = 0; i < nq; ++i) {
+                    const float4 w = wp[i * FPR];
+                    const float4 v = pp[i];
+                    acc0 = fmaf(w.x, v.x, acc0);
+                    acc1 = fmaf(w.y, v.y, acc1);
+                    acc0 = fmaf(w.z, v.z, acc0);
+                    acc1 = fmaf(w.w, v.w, acc1);
+                }
+                const float acc = acc0 + acc1;
+                const int oi = (int)(e.y & 0xffffu);
+                if (oi < n_out) {
+                    mo[oi] = acc;
+                    runmax = fmaxf(runmax, acc);
+                }
+            }
+        }
+    }
+    flush_max(runmax, cur_grp, a.gmax, lane);
+}

@@ -23,6 +23,7 @@
 #include "front_2048.h"
 #include "front_generic.h"
 #include "front_pow2.h"
+#include "front_400.h"
 #include "host_tables.h"
 
 namespace {
@@ -374,7 +375,7 @@ struct mfcc_plan {
     float* d_dct_frag = nullptr;
     float* d_lifter = nullptr;
     float* d_dfrag = nullptr;
-    // power-of-two front end (n_fft 256 / 512 / 1024): 0, or log2(n_fft)
+    // in-register FFT front ends other than 2048: 0, log2(n_fft) for 256 / 512 / 1024, or 400
     int p2_log2n = 0, p2_waves = 0, p2_quads = 0, p2_rounds = 0;
     size_t p2_lds_bytes = 0;
     float2* d_p2_tw1 = nullptr;
@@ -462,28 +463,27 @@ Pow2Fn pow2_pick(bool pw2, bool pcm16) {
     if (pw2) return pcm16 ? k_melspec_pow2<L, W, 0, true> : k_melspec_pow2<L, W, 0, false>;
     return pcm16 ? k_melspec_pow2<L, W, 1, true> : k_melspec_pow2<L, W, 1, false>;
 }
+template <int W>
+Pow2Fn k400_pick(bool pw2, bool pcm16) {
+    if (pw2) return pcm16 ? k_melspec_400<W, 0, true> : k_melspec_400<W, 0, false>;
+    return pcm16 ? k_melspec_400<W, 1, true> : k_melspec_400<W, 1, false>;
+}
+// p2_log2n: 8, 9, 10 for the power-of-two kernels; 400 stands for the 400-point kernel
 Pow2Fn pow2_kernel(const mfcc_plan* p, bool pcm16) {
     const bool pw2 = p->r.c.power == 2.0f;
+    if (p->p2_log2n == 400) return p->p2_waves == 16 ? k400_pick<16>(pw2, pcm16) : k400_pick<8>(pw2, pcm16);
     if (p->p2_log2n == 8) return p->p2_waves == 16 ? pow2_pick<8, 16>(pw2, pcm16) : pow2_pick<8, 8>(pw2, pcm16);
     if (p->p2_log2n == 9) return p->p2_waves == 16 ? pow2_pick<9, 16>(pw2, pcm16) : pow2_pick<9, 8>(pw2, pcm16);
     return p->p2_waves == 16 ? pow2_pick<10, 16>(pw2, pcm16) : pow2_pick<10, 8>(pw2, pcm16);
 }
 
-// Tables of the power-of-two front end.  Returns false when the filterbank does not fit its
-// layout (the dense-DFT kernel takes over).
-template <int L>
-bool build_pow2_tables(mfcc_plan* p, const std::vector<float>& basis, std::vector<float2>& tw1,
-                       std::vector<float4>& melw, std::vector<uint2>& pairs) {
-    using G = kp2::Geo<L>;
-    const double PI = 3.14159265358979323846;
+// Mel tables of the kernels whose mel stage runs lane = (frame, filter) pair (front_pow2.h,
+// front_400.h): T frames per pass, frame t's power spectrum at float p_base(t) of the wavefront's
+// region with room for row_cap floats.  Returns false when the filterbank does not fit.
+template <typename PBase>
+bool build_pair_mel(const mfcc_plan* p, const std::vector<float>& basis, int T, PBase p_base, int row_cap,
+                    std::vector<float4>& melw, std::vector<uint2>& pairs, int* out_quads, int* out_rounds) {
     const int n_mels = p->r.c.n_mels, n_bins = p->r.n_bins;
-    tw1.assign((size_t)std::max(1, G::R - 1) * 64, make_float2(1.0f, 0.0f));
-    for (int k2 = 1; k2 < G::R; ++k2)
-        for (int n1 = 0; n1 < 64; ++n1) {
-            const double ang = -2.0 * PI * (double)(n1 * k2) / (double)G::N;
-            const double sc = (k2 == G::R / 2) ? 1.0 : 0.5;   // rdft_cols leaves 2 A[k] except at k = R/2
-            tw1[(size_t)(k2 - 1) * 64 + n1] = make_float2((float)(sc * std::cos(ang)), (float)(sc * std::sin(ang)));
-        }
     // each filter's span, from a 4-aligned first bin
     std::vector<int> start(n_mels, 0), fq(n_mels, 1);
     for (int f = 0; f < n_mels; ++f) {
@@ -495,13 +495,13 @@ bool build_pow2_tables(mfcc_plan* p, const std::vector<float>& basis, std::vecto
         fq[f] = (hi - start[f]) / 4 + 1;
     }
     // round rd: filters rd fpr .. rd fpr + fpr - 1 for all T frames, as many quads as the widest
-    constexpr int fpr = 64 / G::T;
+    const int fpr = 64 / T;
     const int rounds = (n_mels + fpr - 1) / fpr;
     std::vector<int> nq(rounds, 1), qoff(rounds + 1, 0);
     for (int f = 0; f < n_mels; ++f) nq[f / fpr] = std::max(nq[f / fpr], fq[f]);
     for (int rd = 0; rd < rounds; ++rd) qoff[rd + 1] = qoff[rd] + nq[rd];
     for (int f = 0; f < n_mels; ++f)
-        if (start[f] + 4 * nq[f / fpr] > G::row_cap()) return false;
+        if (start[f] + 4 * nq[f / fpr] > row_cap) return false;
     const int quads = qoff[rounds];
     if ((size_t)quads * fpr > 0xffffu) return false;
     melw.assign((size_t)quads * fpr, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
@@ -519,20 +519,64 @@ bool build_pow2_tables(mfcc_plan* p, const std::vector<float>& basis, std::vecto
                     }
                     melw[(size_t)(qoff[rd] + i) * fpr + fi] = make_float4(w[0], w[1], w[2], w[3]);
                 }
-            for (int t = 0; t < G::T; ++t) {
-                const uint32_t p_off = (uint32_t)(kp2::p_base<L>(t) + (live ? start[f] : 0));
+            for (int t = 0; t < T; ++t) {
+                const uint32_t p_off = (uint32_t)(p_base(t) + (live ? start[f] : 0));
                 const uint32_t w_idx = (uint32_t)(qoff[rd] * fpr + fi);
                 const uint32_t out = live ? (uint32_t)(t * n_mels + f) : 0xffffu;
                 pairs[(size_t)rd * 64 + t * fpr + fi] = make_uint2(p_off | (w_idx << 16), out | ((uint32_t)nq[rd] << 16));
             }
         }
-    p->p2_quads = quads;
-    p->p2_rounds = rounds;
+    *out_quads = quads;
+    *out_rounds = rounds;
+    return true;
+}
+
+// Tables of the power-of-two front end.  Returns false when the filterbank does not fit its
+// layout (the dense-DFT kernel takes over).
+template <int L>
+bool build_pow2_tables(mfcc_plan* p, const std::vector<float>& basis, std::vector<float2>& tw1,
+                       std::vector<float4>& melw, std::vector<uint2>& pairs) {
+    using G = kp2::Geo<L>;
+    const double PI = 3.14159265358979323846;
+    tw1.assign((size_t)std::max(1, G::R - 1) * 64, make_float2(1.0f, 0.0f));
+    for (int k2 = 1; k2 < G::R; ++k2)
+        for (int n1 = 0; n1 < 64; ++n1) {
+            const double ang = -2.0 * PI * (double)(n1 * k2) / (double)G::N;
+            const double sc = (k2 == G::R / 2) ? 1.0 : 0.5;   // rdft_cols leaves 2 A[k] except at k = R/2
+            tw1[(size_t)(k2 - 1) * 64 + n1] = make_float2((float)(sc * std::cos(ang)), (float)(sc * std::sin(ang)));
+        }
+    if (!build_pair_mel(p, basis, G::T, [](int t) { return kp2::p_base<L>(t); }, G::row_cap(), melw, pairs,
+                        &p->p2_quads, &p->p2_rounds))
+        return false;
     p->p2_waves = 0;
     for (int w : {16, 8})
-        if (kp2::lds_bytes(G::REGION, w, fpr, quads, rounds) <= (size_t)k2048::LDS_LIMIT) { p->p2_waves = w; break; }
+        if (kp2::lds_bytes(G::REGION, w, 64 / G::T, p->p2_quads, p->p2_rounds) <= (size_t)k2048::LDS_LIMIT) {
+            p->p2_waves = w;
+            break;
+        }
     if (!p->p2_waves) return false;
-    p->p2_lds_bytes = kp2::lds_bytes(G::REGION, p->p2_waves, fpr, quads, rounds);
+    p->p2_lds_bytes = kp2::lds_bytes(G::REGION, p->p2_waves, 64 / G::T, p->p2_quads, p->p2_rounds);
+    return true;
+}
+
+// Tables of the 400-point front end (front_400.h); false: the dense-DFT kernel takes over.
+bool build_400_tables(mfcc_plan* p, const std::vector<float>& basis, std::vector<float2>& tw1,
+                      std::vector<float4>& melw, std::vector<uint2>& pairs) {
+    const double PI = 3.14159265358979323846;
+    tw1.assign(12 * 16, make_float2(1.0f, 0.0f));
+    for (int c = 1; c <= 12; ++c)
+        for (int b = 0; b < 16; ++b) {
+            const double ang = -2.0 * PI * (double)(b * c) / 400.0;
+            tw1[(size_t)(c - 1) * 16 + b] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+    if (!build_pair_mel(p, basis, k400::T, [](int t) { return k400::p_base(t); }, k400::P_STRIDE, melw, pairs,
+                        &p->p2_quads, &p->p2_rounds))
+        return false;
+    p->p2_waves = 0;
+    for (int w : {16, 8})
+        if (k400::lds_bytes(w, p->p2_quads, p->p2_rounds) <= (size_t)k2048::LDS_LIMIT) { p->p2_waves = w; break; }
+    if (!p->p2_waves) return false;
+    p->p2_lds_bytes = k400::lds_bytes(p->p2_waves, p->p2_quads, p->p2_rounds);
     return true;
 }
 
@@ -710,11 +754,12 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         for (size_t i = 0; i < jobs.size(); ++i)
             jobs[i] = make_int2(4 * p->mj.at[i], 4 * (k2048::MCELL_OFF + p->mj.cell[i]) | (p->mj.cont[i] ? 1 : 0));
     }
-    // n_fft 256 / 512 / 1024: the in-register FFT kernel (MFCC_HIP_DENSE_DFT=1 keeps the dense-DFT one)
+    // n_fft 256 / 400 / 512 / 1024: the in-register FFT kernels (MFCC_HIP_DENSE_DFT=1 keeps the dense-DFT one)
     std::vector<float2> p2_tw1;
     std::vector<float4> p2_melw;
     std::vector<uint2> p2_pairs;
     if (!std::getenv("MFCC_HIP_DENSE_DFT")) {
+        if (r.c.n_fft == 400 && build_400_tables(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 400;
         if (r.c.n_fft == 256 && build_pow2_tables<8>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 8;
         if (r.c.n_fft == 512 && build_pow2_tables<9>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 9;
         if (r.c.n_fft == 1024 && build_pow2_tables<10>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 10;
@@ -847,7 +892,7 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
         pa.reflect = plan->r.c.pad_mode == MFCC_PAD_REFLECT;
         pa.pw_mode = plan->r.c.power == 2.0f ? 0 : (plan->r.c.power == 1.0f ? 1 : 2);
         pa.half_power = 0.5f * plan->r.c.power;
-        const int passes_per_tile = (1 << plan->p2_log2n) / 128;
+        const int passes_per_tile = plan->p2_log2n == 400 ? 4 : (1 << plan->p2_log2n) / 128;
         const int64_t wg_needed = (L.ub_tiles * passes_per_tile + plan->p2_waves - 1) / plan->p2_waves;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(wg_needed, plan->n_cu));
         if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
@@ -1019,6 +1064,7 @@ int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_
 const char* mfcc_plan_front_kernel(const mfcc_plan* plan) {
     if (!plan) return nullptr;
     if (plan->fast2048) return "fft2048";
+    if (plan->p2_log2n == 400) return "fft400";
     if (plan->p2_log2n == 8) return "fft256";
     if (plan->p2_log2n == 9) return "fft512";
     if (plan->p2_log2n == 10) return "fft1024";

@@ -62,6 +62,7 @@ def test_reference_default_one_utterance(S):
     dict(n_fft=512, hop_length=128, pad_mode="reflect", n_mels=64),
     dict(n_fft=400, hop_length=160, n_mels=80, sr=16000, center=False),
     dict(n_fft=254, hop_length=77, n_mels=20, sr=8000),
+    dict(n_fft=320, hop_length=160, n_mels=40, sr=16000),          # dense-DFT kernel
 ])
 def test_melspectrogram_parity(S, kw):
     y = speech_like(41234, seed=3)
