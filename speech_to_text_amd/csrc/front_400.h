@@ -41,43 +41,6 @@ constexpr size_t lds_bytes(int waves, int mel_quads, int mel_rounds) {
                             2 * 64 * (size_t)mel_rounds + 4 /* unit counter */);
 }
 
-// cos, sin of 2 pi j / 25
-constexpr float C25[25] = {
-    1.0f, 0.96858316112863108f, 0.87630668004386358f, 0.72896862742141155f, 0.53582679497899655f,
-    0.30901699437494745f, 0.062790519529313527f, -0.1873813145857246f, -0.42577929156507272f,
-    -0.63742398974868975f, -0.80901699437494734f, -0.92977648588825135f, -0.99211470131447776f,
-    -0.99211470131447788f, -0.92977648588825146f, -0.80901699437494778f, -0.63742398974868952f,
-    -0.42577929156507216f, -0.18738131458572463f, 0.062790519529312833f, 0.30901699437494723f,
-    0.53582679497899677f, 0.72896862742141122f, 0.87630668004386314f, 0.96858316112863097f};
-constexpr float S25[25] = {
-    0.0f, 0.24868988716485479f, 0.48175367410171532f, 0.68454710592868862f, 0.84432792550201508f,
-    0.95105651629515353f, 0.99802672842827156f, 0.98228725072868872f, 0.90482705246601947f,
-    0.77051324277578925f, 0.58778525229247325f, 0.36812455268467814f, 0.12533323356430454f,
-    -0.12533323356430429f, -0.36812455268467792f, -0.58778525229247269f, -0.77051324277578936f,
-    -0.9048270524660198f, -0.98228725072868872f, -0.99802672842827156f, -0.95105651629515364f,
-    -0.84432792550201496f, -0.68454710592868895f, -0.4817536741017161f, -0.24868988716485535f};
-
-// Real 25-point DFT, bins 0..12: Y[c] = sum_a x[a] exp(-2 pi i a c / 25).
-__host__ __device__ __forceinline__ void rdft25(const float (&x)[25], float (&yr)[13], float (&yi)[13]) {
-    float e[13], o[13];
-    e[0] = x[0]; o[0] = 0.0f;
-#pragma unroll
-    for (int a = 1; a <= 12; ++a) { e[a] = x[a] + x[25 - a]; o[a] = x[a] - x[25 - a]; }
-    float s = e[0];
-#pragma unroll
-    for (int a = 1; a <= 12; ++a) s += e[a];
-    yr[0] = s; yi[0] = 0.0f;
-#pragma unroll
-    for (int c = 1; c <= 12; ++c) {
-        float re = e[0], im = 0.0f;
-#pragma unroll
-        for (int a = 1; a <= 12; ++a) {
-            re = fmaf(e[a], C25[(a * c) % 25], re);
-            im = fmaf(o[a], -S25[(a * c) % 25], im);
-        }
-        yr[c] = re; yi[c] = im;
-    }
-}
 }  // namespace k400
 
 // Pow2Args with tw1 = W_400^(b c) as [c - 1][b] (12 x 16); w64 and tw128 are unused.
@@ -192,7 +155,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_400(const Pow2Args a) {
         // ---- step 1: real DFT-25 over a, twiddle, exchange -----------------------------------------
         {
             float yr[NC], yi[NC];
-            rdft25(x, yr, yi);
+            fc::rdft25(x, yr, yi);
             float2 tw[NC];
 #pragma unroll
             for (int c = 1; c < NC; ++c) tw[c] = tw_l[(c - 1) * 16 + b];

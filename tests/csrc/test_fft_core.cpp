@@ -29,10 +29,28 @@ static double check_rdft_cols() {
     return worst;
 }
 
+static double check_rdft25() {
+    const double PI = 3.14159265358979323846;
+    double worst = 0.0;
+    for (int trial = 0; trial < 50; ++trial) {
+        float x[25], yr[13], yi[13]; double xd[25];
+        for (int n = 0; n < 25; ++n) xd[n] = x[n] = (float)rand() / RAND_MAX - 0.5f;
+        fc::rdft25(x, yr, yi);
+        for (int k = 0; k < 13; ++k) {
+            double sr = 0, si = 0;
+            for (int n = 0; n < 25; ++n) { sr += xd[n] * cos(2 * PI * n * k / 25); si -= xd[n] * sin(2 * PI * n * k / 25); }
+            worst = fmax(worst, fabs(sr - yr[k]));
+            worst = fmax(worst, fabs(si - yi[k]));
+        }
+    }
+    return worst;
+}
+
 int main() {
     const double PI = 3.14159265358979323846;
     double worst = 0.0;
     srand(7);
+    worst = fmax(worst, check_rdft25());
     worst = fmax(worst, check_rdft_cols<2>());
     worst = fmax(worst, check_rdft_cols<4>());
     worst = fmax(worst, check_rdft_cols<8>());

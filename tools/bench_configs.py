@@ -6,9 +6,10 @@
 config 3  1000 h: the 10 h resident batch looped 100 times, HIP-event kernel times (no new
           audio is generated per pass; a 1000 h corpus does not fit one GPU, each rank would
           stream its share through resident batches of this size)
-config 4  ASR front end: sr 16000, hop 160, 80 mels, 13 MFCC with n_fft = 400 (dense-DFT kernel)
-          and with n_fft = 512 / win_length = 400 (the 400-sample window zero-padded to a
-          512-point FFT; in-register FFT kernel), + global CMVN (accumulate, apply)
+config 4  ASR front end: sr 16000, hop 160, 80 mels, 13 MFCC with n_fft = 400 (25 x 16 in-register
+          DFT kernel) and with n_fft = 512 / win_length = 400 (the 400-sample window zero-padded
+          to a 512-point FFT; in-register FFT kernel), + global CMVN (accumulate, apply)
+extra     n_fft = 480 (30 ms), which no in-register kernel covers: the dense-DFT (MFMA) kernel
 config 5  long utterances U(30, 60) s, one of them silent but for a click
 
 Each entry: audio-hours/s from wall time over whole steps (synchronised), per-kernel HIP-event
@@ -103,6 +104,8 @@ def main():
     results["config4_nfft400_cmvn"] = run(asr400, pcm, so, steps=10, warmup=2, with_cmvn=True)
     asr512 = S.make_config(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13)
     results["config4_nfft512_win400_cmvn"] = run(asr512, pcm, so, steps=10, warmup=2, with_cmvn=True)
+    asr480 = S.make_config(sr=16000, n_fft=480, hop_length=160, n_mels=80, n_mfcc=13)
+    results["extra_nfft480_dense_dft"] = run(asr480, pcm, so, steps=5, warmup=2)
     del pcm
 
     pcm5, so5 = make_batch(args.hours, 5, dev, lo_s=30.0, hi_s=60.0)
