@@ -63,6 +63,10 @@ def test_reference_default_one_utterance(S):
     dict(n_fft=400, hop_length=160, n_mels=80, sr=16000, center=False),
     dict(n_fft=254, hop_length=77, n_mels=20, sr=8000),
     dict(n_fft=320, hop_length=160, n_mels=40, sr=16000),          # dense-DFT kernel
+    dict(n_fft=512, hop_length=160, n_mels=10, sr=16000),          # wide filters on the 512-point kernel
+    dict(n_fft=1024, hop_length=256, n_mels=256, sr=44100),        # 16 mel rounds of 32 filters
+    dict(n_fft=400, hop_length=160, n_mels=1, sr=16000),
+    dict(n_fft=256, hop_length=128, n_mels=64, sr=8000, htk=True),
 ])
 def test_melspectrogram_parity(S, kw):
     y = speech_like(41234, seed=3)
