@@ -26,7 +26,7 @@
 #include "front_pow2.h"
 
 namespace k400 {
-constexpr int N = 400, NB = 201, T = 4, NA = 25, NBL = 16, NC = 13;
+constexpr int N = 400, NB = 201, T = 4, NA = 25, NC = 13;   // NA samples per lane, NC columns per frame
 constexpr int COL = 36;                 // floats per exchange column: 16 complex + 4 floats of padding
 constexpr int REGION = k2048::XCH_FLOATS;
 constexpr int P_STRIDE = 272;           // frame t's power spectrum starts at float 272 t: the bases

@@ -375,8 +375,9 @@ struct mfcc_plan {
     float* d_dct_frag = nullptr;
     float* d_lifter = nullptr;
     float* d_dfrag = nullptr;
-    // in-register FFT front ends other than 2048: 0, log2(n_fft) for 256 / 512 / 1024, or 400
-    int p2_log2n = 0, p2_waves = 0, p2_quads = 0, p2_rounds = 0;
+    // in-register FFT front ends other than 2048: 0 (none), 8 / 9 / 10 = log2(n_fft) for the
+    // power-of-two kernel (front_pow2.h), or 400 for the 400-point kernel (front_400.h)
+    int small_fft = 0, p2_waves = 0, p2_quads = 0, p2_rounds = 0;
     size_t p2_lds_bytes = 0;
     float2* d_p2_tw1 = nullptr;
     float4* d_p2_melw = nullptr;
@@ -468,12 +469,12 @@ Pow2Fn k400_pick(bool pw2, bool pcm16) {
     if (pw2) return pcm16 ? k_melspec_400<W, 0, true> : k_melspec_400<W, 0, false>;
     return pcm16 ? k_melspec_400<W, 1, true> : k_melspec_400<W, 1, false>;
 }
-// p2_log2n: 8, 9, 10 for the power-of-two kernels; 400 stands for the 400-point kernel
+// small_fft: 8, 9, 10 for the power-of-two kernels; 400 stands for the 400-point kernel
 Pow2Fn pow2_kernel(const mfcc_plan* p, bool pcm16) {
     const bool pw2 = p->r.c.power == 2.0f;
-    if (p->p2_log2n == 400) return p->p2_waves == 16 ? k400_pick<16>(pw2, pcm16) : k400_pick<8>(pw2, pcm16);
-    if (p->p2_log2n == 8) return p->p2_waves == 16 ? pow2_pick<8, 16>(pw2, pcm16) : pow2_pick<8, 8>(pw2, pcm16);
-    if (p->p2_log2n == 9) return p->p2_waves == 16 ? pow2_pick<9, 16>(pw2, pcm16) : pow2_pick<9, 8>(pw2, pcm16);
+    if (p->small_fft == 400) return p->p2_waves == 16 ? k400_pick<16>(pw2, pcm16) : k400_pick<8>(pw2, pcm16);
+    if (p->small_fft == 8) return p->p2_waves == 16 ? pow2_pick<8, 16>(pw2, pcm16) : pow2_pick<8, 8>(pw2, pcm16);
+    if (p->small_fft == 9) return p->p2_waves == 16 ? pow2_pick<9, 16>(pw2, pcm16) : pow2_pick<9, 8>(pw2, pcm16);
     return p->p2_waves == 16 ? pow2_pick<10, 16>(pw2, pcm16) : pow2_pick<10, 8>(pw2, pcm16);
 }
 
@@ -759,13 +760,13 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
     std::vector<float4> p2_melw;
     std::vector<uint2> p2_pairs;
     if (!std::getenv("MFCC_HIP_DENSE_DFT")) {
-        if (r.c.n_fft == 400 && build_400_tables(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 400;
-        if (r.c.n_fft == 256 && build_pow2_tables<8>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 8;
-        if (r.c.n_fft == 512 && build_pow2_tables<9>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 9;
-        if (r.c.n_fft == 1024 && build_pow2_tables<10>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->p2_log2n = 10;
+        if (r.c.n_fft == 400 && build_400_tables(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 400;
+        if (r.c.n_fft == 256 && build_pow2_tables<8>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 8;
+        if (r.c.n_fft == 512 && build_pow2_tables<9>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 9;
+        if (r.c.n_fft == 1024 && build_pow2_tables<10>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 10;
     }
     std::vector<float> dfrag;
-    if (!p->fast2048 && !p->p2_log2n) {
+    if (!p->fast2048 && !p->small_fft) {
         // Dense DFT matrix [n_fft x 2 n_bins], columns interleaved (cos, -sin), in the B-fragment
         // order of v_mfma_f32_16x16x4_f32: lane l supplies B[k = l >> 4][j = l & 15].
         const int N = r.c.n_fft;
@@ -834,10 +835,10 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
     if (rc == MFCC_OK) rc = upload(frag, &p->d_dct_frag);
     if (rc == MFCC_OK) rc = upload(lifter, &p->d_lifter);
     if (rc == MFCC_OK) rc = upload(dfrag, &p->d_dfrag);
-    if (rc == MFCC_OK && p->p2_log2n) rc = upload(p2_tw1, &p->d_p2_tw1);
-    if (rc == MFCC_OK && p->p2_log2n) rc = upload(p2_melw, &p->d_p2_melw);
-    if (rc == MFCC_OK && p->p2_log2n) rc = upload(p2_pairs, &p->d_p2_pairs);
-    if (rc == MFCC_OK) rc = p->fast2048 ? select_variant(p) : (p->p2_log2n ? setup_pow2(p) : setup_generic(p));
+    if (rc == MFCC_OK && p->small_fft) rc = upload(p2_tw1, &p->d_p2_tw1);
+    if (rc == MFCC_OK && p->small_fft) rc = upload(p2_melw, &p->d_p2_melw);
+    if (rc == MFCC_OK && p->small_fft) rc = upload(p2_pairs, &p->d_p2_pairs);
+    if (rc == MFCC_OK) rc = p->fast2048 ? select_variant(p) : (p->small_fft ? setup_pow2(p) : setup_generic(p));
     if (rc != MFCC_OK) {
         const std::string keep = g_err;
         mfcc_plan_destroy(p);
@@ -880,7 +881,7 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     hipLaunchKernelGGL(k_prepare_tiles, dim3(pt_blocks), dim3(256), 0, st, d_sample_offsets,
                        d_frame_offsets, d_group, tile_off, n_utts, tiles);
 
-    if (plan->p2_log2n) {
+    if (plan->small_fft) {
         Pow2Args pa;
         pa.pcm = d_pcm; pa.tiles = tiles; pa.hdr = hdr;
         pa.window = plan->d_window; pa.tw1 = plan->d_p2_tw1; pa.w64 = plan->d_w64; pa.tw128 = plan->d_tw128;
@@ -892,7 +893,7 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
         pa.reflect = plan->r.c.pad_mode == MFCC_PAD_REFLECT;
         pa.pw_mode = plan->r.c.power == 2.0f ? 0 : (plan->r.c.power == 1.0f ? 1 : 2);
         pa.half_power = 0.5f * plan->r.c.power;
-        const int passes_per_tile = plan->p2_log2n == 400 ? 4 : (1 << plan->p2_log2n) / 128;
+        const int passes_per_tile = plan->small_fft == 400 ? 4 : (1 << plan->small_fft) / 128;
         const int64_t wg_needed = (L.ub_tiles * passes_per_tile + plan->p2_waves - 1) / plan->p2_waves;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(wg_needed, plan->n_cu));
         if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
@@ -1064,10 +1065,10 @@ int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_
 const char* mfcc_plan_front_kernel(const mfcc_plan* plan) {
     if (!plan) return nullptr;
     if (plan->fast2048) return "fft2048";
-    if (plan->p2_log2n == 400) return "fft400";
-    if (plan->p2_log2n == 8) return "fft256";
-    if (plan->p2_log2n == 9) return "fft512";
-    if (plan->p2_log2n == 10) return "fft1024";
+    if (plan->small_fft == 400) return "fft400";
+    if (plan->small_fft == 8) return "fft256";
+    if (plan->small_fft == 9) return "fft512";
+    if (plan->small_fft == 10) return "fft1024";
     return "dense_dft";
 }
 
