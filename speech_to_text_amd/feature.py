@@ -172,32 +172,30 @@ def _valid_audio(y) -> None:
         raise ParameterError("Audio buffer is not finite everywhere")
 
 
-def _upload_ragged(chans: Sequence, device, dtype=np.float32) -> (torch.Tensor, np.ndarray):
+def _upload_ragged(chans: Sequence, device, dtype=np.float32, try_int16: bool = False) -> (torch.Tensor, np.ndarray):
+    """Concatenates the utterances on the device.  Host arrays go through the pinned, chunked,
+    multi-threaded path of staging.py; with try_int16 float waveforms on the int16 grid are
+    uploaded as 16-bit PCM."""
+    from . import staging
+
     lens = np.array([int(c.shape[-1]) for c in chans], dtype=np.int64)
     so = np.zeros(len(chans) + 1, dtype=np.int64)
     np.cumsum(lens, out=so[1:])
     total = int(so[-1])
     if dtype == np.int16:
-        host = np.empty(max(total, 1), dtype=np.int16)
-        host[:1] = 0
-        for c, a, b in zip(chans, so[:-1], so[1:]):
-            host[a:b] = np.asarray(c).reshape(-1)
-        return torch.from_numpy(host).to(device), so
+        host = [np.asarray(c).reshape(-1) for c in chans]
+        return staging.upload_ragged(host, so, device, "i16")[0], so
     if all(isinstance(c, torch.Tensor) and c.is_cuda for c in chans) and len(chans) > 0:
         pcm = torch.cat([c.reshape(-1).to(device=device, dtype=torch.float32) for c in chans]) if total else \
-            torch.empty(0, dtype=torch.float32, device=device)
-    else:
-        host = np.empty(total, dtype=np.float32)
-        for c, a, b in zip(chans, so[:-1], so[1:]):
-            host[a:b] = c.detach().cpu().numpy().reshape(-1) if isinstance(c, torch.Tensor) else np.asarray(c).reshape(-1)
-        pcm = torch.from_numpy(host).to(device)
-    if pcm.numel() == 0:
-        pcm = torch.zeros(1, dtype=torch.float32, device=device)
+            torch.zeros(1, dtype=torch.float32, device=device)
+        return pcm, so
+    host = [(c.detach().cpu().numpy() if isinstance(c, torch.Tensor) else np.asarray(c)).reshape(-1) for c in chans]
+    pcm, _ = staging.upload_ragged(host, so, device, "f32_to_i16" if try_int16 else "f32")
     return pcm, so
 
 
 def _run_batch(chans: Sequence, config: MfccConfig, *, groups: Optional[np.ndarray], device,
-               what: str = "mfcc"):
+               what: str = "mfcc", try_int16: bool = False, check_finite: bool = False):
     """chans: 1-D arrays.  Returns (device tensor (total_frames, width), frame_offsets)."""
     plan = get_plan(config, device)
     for c in chans:
@@ -207,7 +205,9 @@ def _run_batch(chans: Sequence, config: MfccConfig, *, groups: Optional[np.ndarr
         if config.center and config.pad_mode == "reflect" and c.shape[-1] == 0:
             raise ParameterError("can't extend an empty signal with pad_mode='reflect'")
     pcm16 = len(chans) > 0 and all(isinstance(c, np.ndarray) and c.dtype == np.int16 for c in chans)
-    pcm, so = _upload_ragged(chans, plan.device, np.int16 if pcm16 else np.float32)
+    pcm, so = _upload_ragged(chans, plan.device, np.int16 if pcm16 else np.float32, try_int16=try_int16)
+    if check_finite and pcm.dtype == torch.float32 and not bool(torch.isfinite(pcm).all()):
+        raise ParameterError("Audio buffer is not finite everywhere")      # librosa.util.valid_audio
     fo = plan.frame_offsets(so)
     total_frames = int(fo[-1])
     d_so = torch.from_numpy(so).to(plan.device)
@@ -296,13 +296,16 @@ def spectrogram(*, y=None, n_fft=2048, hop_length=512, power=1.0, device=None, v
 
 
 def mfcc_batch(ys: Sequence, *, sr=22050, n_mfcc=20, dct_type=2, norm="ortho", lifter=0, device=None,
-               validate=True, return_tensor=False, **kwargs) -> List:
+               validate=True, return_tensor=False, int16_if_exact=False, **kwargs) -> List:
     """Ragged batch: ``ys`` is a sequence of mono utterances, each ``(T_i,)`` or ``(1, T_i)``
     (the waveform layout of a LibriSpeech item, /root/reference/src/preprocess.py:132).
 
     If every utterance is a numpy int16 array the batch is taken as 16-bit PCM (sample value
     ``y / 32768``, what torchaudio decodes LibriSpeech FLAC into): half the upload, same result
     as the float32 waveform.  (``mfcc`` itself stays strict, like librosa: floating point only.)
+    With ``int16_if_exact`` float waveforms are converted to that form while they are staged for
+    upload whenever all of them lie on the int16 grid (bit-identical output, half the upload).
+    The finiteness check of ``librosa.util.valid_audio`` runs on the device, on the uploaded batch.
 
     Returns one ``(n_frames_i, n_mfcc)`` float32 C-contiguous array per utterance -- exactly
     ``librosa.feature.mfcc(y=y_i, ...)[0].T`` as written to HDF5 at
@@ -318,12 +321,11 @@ def mfcc_batch(ys: Sequence, *, sr=22050, n_mfcc=20, dct_type=2, norm="ortho", l
             y = y[0]
         if y.ndim != 1:
             raise ParameterError(f"mfcc_batch takes mono utterances, got shape {tuple(y.shape)}")
-        if validate and not pcm16:
-            _valid_audio(y)
         chans.append(y)
     if not chans:
         return []
-    out, fo = _run_batch(chans, config, groups=None, device=device)
+    out, fo = _run_batch(chans, config, groups=None, device=device, try_int16=int16_if_exact and not pcm16,
+                         check_finite=validate and not pcm16)
     if return_tensor:
         return [out[int(a):int(b)] for a, b in zip(fo[:-1], fo[1:])]
     host = out.cpu().numpy()

@@ -123,12 +123,8 @@ class Preprocessor:
             return self._extract(waveforms, n_fft=self.n_fft, hop_length=self.hop_length, n_mfcc=self.n_mfcc)
         from .feature import mfcc_batch
 
-        if self.ingest == "int16":
-            as16 = [to_int16_pcm(w) for w in waveforms]
-            if all(w is not None for w in as16):
-                waveforms = as16
         return mfcc_batch(waveforms, n_fft=self.n_fft, hop_length=self.hop_length, n_mfcc=self.n_mfcc,
-                          device=self.device)
+                          device=self.device, int16_if_exact=self.ingest == "int16")
 
     def _write(self, item: Item, frames: np.ndarray) -> None:
         _, sample_rate, transcript, speaker_id, chapter_id, utterance_id = item

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Wall-clock rate of the whole drop-in step -- host waveforms in, HDF5 features out -- through
+Preprocessor.preprocess (the reference's `--preprocess`, /root/reference/src/preprocess.py:146-167):
+
+    python tools/bench_preprocess.py [--hours H] [--out file.json]
+
+Variants: one HDF5 file per utterance as the reference writes them (writer threads), one packed
+file per rank, and the packed file with 16-bit PCM ingest.  The waveforms are synthetic
+(LibriSpeech-like lengths, values on the int16 grid) and already decoded in host memory: FLAC
+decode is outside this path."""
+from __future__ import annotations
+
+import argparse
+import json
+import shutil
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import speech_to_text_amd as S  # noqa: E402
+
+SR = 16000
+
+
+def make_items(hours: float, seed: int = 3):
+    rng = np.random.default_rng(seed)
+    items, total, u = [], 0, 0
+    target = int(hours * 3600 * SR)
+    while total < target:
+        n = int(rng.uniform(2.0, 35.0) * SR)
+        y = (rng.integers(-20000, 20000, size=n, dtype=np.int32).astype(np.float32) / 32768.0)
+        items.append((y[None, :], SR, f"TRANSCRIPT NUMBER {u} OF THE SYNTHETIC SET", 100 + u % 40, 2000 + u % 7, u))
+        total += n
+        u += 1
+    return items, total / SR / 3600.0
+
+
+def timed(fn):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hours", type=float, default=10.0)
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    items, hours = make_items(args.hours)
+    base = Path(tempfile.mkdtemp(prefix="mfcc_pre_", dir="/dev/shm" if Path("/dev/shm").exists() else None))
+    res = {"audio_hours": hours, "utterances": len(items)}
+    try:
+        S.mfcc_batch([items[0][0][0]], n_fft=2048, hop_length=512, n_mfcc=13)      # plan + library warm-up
+        waves = [it[0][0] for it in items]
+        dt, feats = timed(lambda: S.mfcc_batch(waves, n_fft=2048, hop_length=512, n_mfcc=13))
+        res["mfcc_batch_host_to_host"] = {"seconds": dt, "audio_hours_per_s": hours / dt,
+                                          "note": "host float32 waveforms -> host (F, 13) arrays, no files"}
+        del feats
+        for name, kw, pkw in (("files_per_utterance", {}, dict(multiprocess=True)),
+                              ("packed_file", {}, dict(multiprocess=True, packed=True)),
+                              ("packed_file_int16_ingest", dict(ingest="int16"), dict(multiprocess=True, packed=True))):
+            out = base / name
+            pre = S.Preprocessor(items, str(out), **kw)
+            dt, n = timed(lambda: pre.preprocess(verbose=False, **pkw))
+            files = sum(1 for _ in out.iterdir())
+            size = sum(f.stat().st_size for f in out.iterdir())
+            res[name] = {"seconds": dt, "audio_hours_per_s": hours / dt, "utterances": int(n), "files": files,
+                         "bytes_written": size}
+            shutil.rmtree(out)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    text = json.dumps(res, indent=1)
+    print(text)
+    if args.out:
+        Path(args.out).write_text(text)
+
+
+if __name__ == "__main__":
+    main()
