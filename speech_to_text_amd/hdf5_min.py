@@ -69,6 +69,10 @@ def _object_header(messages: bytes, n_messages: int) -> bytes:
     return struct.pack("<BxHII4x", 1, n_messages, 1, len(messages)) + messages
 
 
+_DT_F32, _DT_I64, _DT_VLEN_UTF8, _DS_SCALAR = _dt_f32(), _dt_i64(), _dt_vlen_utf8(), _ds_simple(())
+_MSG_FILL = _message(0x0005, struct.pack("<BBBBI", 2, 2, 2, 1, 0))
+
+
 # ---- writer -----------------------------------------------------------------------------------
 GCOL_MAX_OBJECTS = 60000          # object indices in a global heap collection are 16-bit
 GCOL_MAX_BYTES = 1 << 26
@@ -143,21 +147,30 @@ def write_datasets(path, datasets) -> None:
                 raise TypeError(f"attribute {k!r}: only int and str are supported, got {type(v).__name__}")
         prepared[-1]["aref"] = aref
 
-    def dataset_header(d, gaddr, a_data) -> bytes:
-        dt = {"f32": _dt_f32(), "i64": _dt_i64(), "str": _dt_vlen_utf8()}[d["kind"]]
+    def dataset_header(d):
+        """The dataset's object header with zeroed addresses, and where they go: the offset of
+        the data address and (offset, collection) of every global-heap address."""
+        dt = {"f32": _DT_F32, "i64": _DT_I64, "str": _DT_VLEN_UTF8}[d["kind"]]
         msgs = [
             _message(0x0001, _ds_simple(d["shape"])),
             _message(0x0003, dt, flags=1),                           # constant message
-            _message(0x0005, struct.pack("<BBBBI", 2, 2, 2, 1, 0)),  # fill value: default, alloc late
-            _message(0x0008, struct.pack("<BBQQ", 3, 1, a_data if d["nbytes"] else UNDEF, d["nbytes"])),
+            _MSG_FILL,                                               # fill value: default, alloc late
         ]
+        pos = 16 + sum(len(m) for m in msgs)                         # 16: object header prefix
+        data_at = pos + 8 + 2                                        # message header, version, class
+        msgs.append(_message(0x0008, struct.pack("<BBQQ", 3, 1, 0, d["nbytes"])))
+        pos += len(msgs[-1])
+        heap_at = []
         for k, v in d["attrs"].items():
             if isinstance(v, str):
                 c, idx, ln = d["aref"][k]
-                msgs.append(_attribute(k, _dt_vlen_utf8(), _ds_simple(()), struct.pack("<IQI", ln, gaddr[c], idx)))
+                m = _attribute(k, _DT_VLEN_UTF8, _DS_SCALAR, struct.pack("<IQI", ln, 0, idx))
+                heap_at.append((pos + len(m) - 16 + 4, c))           # the 16 data bytes close the message
             else:
-                msgs.append(_attribute(k, _dt_i64(), _ds_simple(()), struct.pack("<q", int(v))))
-        return _object_header(b"".join(msgs), len(msgs))
+                m = _attribute(k, _DT_I64, _DS_SCALAR, struct.pack("<q", int(v)))
+            msgs.append(m)
+            pos += len(m)
+        return bytearray(_object_header(b"".join(msgs), len(msgs))), data_at, heap_at
 
     # fixed-size pieces first, to know the addresses
     SB, ROOT_OH, BTREE, HEAP_HDR, SNOD = 96, 40, 544, 32, 328
@@ -172,11 +185,11 @@ def write_datasets(path, datasets) -> None:
     a_heap_data = a_heap + HEAP_HDR
     a_snod = a_heap_data + len(heap_data)
     a = a_snod + SNOD
-    a_dset = []
-    dummy = [0] * len(strings.collections)
+    a_dset, headers = [], []
     for d in prepared:
         a_dset.append(a)
-        a += len(dataset_header(d, dummy, 0))
+        headers.append(dataset_header(d))
+        a += len(headers[-1][0])
     gaddr, a = strings.addresses(a) if not strings.empty else ([], a)
     a_data = []
     for d in prepared:
@@ -203,8 +216,11 @@ def write_datasets(path, datasets) -> None:
     with open(path, "wb") as f:
         for part in (sb, root, btree, heap, heap_data, snod):
             f.write(part)
-        for d, ad in zip(prepared, a_data):
-            f.write(dataset_header(d, gaddr or dummy, ad))
+        for d, ad, (hdr, data_at, heap_at) in zip(prepared, a_data, headers):
+            struct.pack_into("<Q", hdr, data_at, ad if d["nbytes"] else UNDEF)
+            for at, c in heap_at:
+                struct.pack_into("<Q", hdr, at, gaddr[c])
+            f.write(hdr)
         for c in range(len(gaddr)):
             f.write(strings.encode(c))
         for d in prepared:

@@ -133,6 +133,10 @@ class Preprocessor:
                            utterance_id=utterance_id, sample_rate=sample_rate, transcript=transcript,
                            backend=self.hdf5_backend)
 
+    def _write_many(self, pairs) -> None:
+        for item, frames in pairs:
+            self._write(item, frames)
+
     def process_audio(self, item: Item) -> None:
         """/root/reference/src/preprocess.py:131-144 for one item."""
         self.out_dir.mkdir(parents=True, exist_ok=True)
@@ -155,7 +159,16 @@ class Preprocessor:
         mine = lpt_shards(costs, self.world_size)[self.rank] if self.world_size > 1 else np.arange(len(items))
         sr = int(items[0][1]) if items else 16000
         batches = pack_batches(lengths[mine], int(self.max_batch_seconds * sr))
-        n_threads = max(1, min(16, (os.cpu_count() or 2) - 1)) if multiprocess else 1
+        # the built-in writer holds the GIL (more threads only add hand-overs); h5py releases it
+        # around its file I/O
+        n_threads = 1
+        if multiprocess and self.hdf5_backend != "min":
+            try:
+                import h5py  # noqa: F401,WPS433
+
+                n_threads = max(1, min(4, (os.cpu_count() or 2) - 1))
+            except ImportError:
+                pass
         if verbose:
             print(f"Processing audio data... rank {self.rank}/{self.world_size}: {len(mine)} of {len(items)} "
                   f"utterances in {len(batches)} GPU batch(es), {n_threads} writer thread(s)")
@@ -173,7 +186,11 @@ class Preprocessor:
                     kept_idx.extend(int(i) for i in idx)
                     pending = []
                 else:
-                    pending = [pool.submit(self._write, items[i], fr) for i, fr in zip(idx, feats)]
+                    # one task per writer thread: the writers are Python code, so a task per file
+                    # costs more in hand-over than the file itself
+                    pairs = [(items[i], fr) for i, fr in zip(idx, feats)]
+                    step = -(-len(pairs) // n_threads)
+                    pending = [pool.submit(self._write_many, pairs[k:k + step]) for k in range(0, len(pairs), step)]
                 done += len(idx)
                 if verbose:
                     print(f"Progress: {done}/{len(mine)}", end="\r")
