@@ -65,6 +65,11 @@ def main():
         res["mfcc_batch_host_to_host"] = {"seconds": dt, "audio_hours_per_s": hours / dt,
                                           "note": "host float32 waveforms -> host (F, 13) arrays, no files"}
         del feats
+        waves16 = [np.rint(w * 32768.0).astype(np.int16) for w in waves]
+        dt, feats = timed(lambda: S.mfcc_batch(waves16, n_fft=2048, hop_length=512, n_mfcc=13))
+        res["mfcc_batch_int16_host_to_host"] = {"seconds": dt, "audio_hours_per_s": hours / dt,
+                                                "note": "host int16 PCM arrays -> host (F, 13) arrays, no files"}
+        del feats, waves16
         for name, kw, pkw in (("files_per_utterance", {}, dict(multiprocess=True)),
                               ("packed_file", {}, dict(multiprocess=True, packed=True)),
                               ("packed_file_int16_ingest", dict(ingest="int16"), dict(multiprocess=True, packed=True))):
