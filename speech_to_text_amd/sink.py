@@ -124,7 +124,7 @@ class FeatureDataset:
 
     def __init__(self, data, *, device=None, n_fft=2048, hop_length=512, n_mfcc=13, max_batch_seconds=1800.0,
                  ingest="float32", extractor=None):
-        from .preprocess import _waveform_to_numpy, to_int16_pcm
+        from .preprocess import _waveform_to_numpy
         from .shard import pack_batches
 
         items = list(data)
@@ -135,17 +135,13 @@ class FeatureDataset:
         self._feats = [None] * len(items)
         for b in pack_batches(lengths, int(max_batch_seconds * sr)):
             chunk = [waves[i] for i in b]
-            if ingest == "int16":
-                as16 = [to_int16_pcm(w) for w in chunk]
-                if all(w is not None for w in as16):
-                    chunk = as16
             if extractor is not None:
                 outs = extractor(chunk, n_fft=n_fft, hop_length=hop_length, n_mfcc=n_mfcc)
             else:
                 from .feature import mfcc_batch
 
                 outs = mfcc_batch(chunk, n_fft=n_fft, hop_length=hop_length, n_mfcc=n_mfcc, device=device,
-                                  return_tensor=True)
+                                  return_tensor=True, int16_if_exact=ingest == "int16")
             for i, o in zip(b, outs):
                 self._feats[int(i)] = o
 
