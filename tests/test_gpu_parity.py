@@ -243,3 +243,33 @@ def test_full_size_batch_properties(S):
     # the floor moves with the maximum, so the shift holds for clamped bands too.
     np.testing.assert_allclose(out2[:, 0], out[:, 0] + shift, rtol=0, atol=5e-3)
     np.testing.assert_allclose(out2[:, 1:], out[:, 1:], rtol=0, atol=5e-3)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
+    dict(n_fft=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
+])
+def test_full_size_batch_properties_asr_front_ends(S, kw):
+    """The 16 kHz front ends (BASELINE config 4) at a 2-hour slice of the bench batch: frame
+    counts, spot utterances against the oracle, and the scaling property of the other test."""
+    import torch
+
+    from bench import make_batch
+
+    dev = torch.device("cuda", 0)
+    cfg = S.make_config(**kw)
+    plan = S.get_plan(cfg, dev)
+    assert plan.front_kernel == f"fft{kw['n_fft']}"
+    pcm, so = make_batch(2.0, seed=98, device=dev)
+    fo = plan.frame_offsets(so)
+    assert np.array_equal(np.diff(fo), 1 + np.diff(so) // kw["hop_length"])
+    d_so, d_fo = torch.from_numpy(so).to(dev), torch.from_numpy(fo).to(dev)
+    out = plan.execute(pcm, d_so, d_fo, int(fo[-1])).cpu().numpy()
+    assert np.isfinite(out).all()
+    for u in (0, len(so) // 3, len(so) - 2):
+        y = pcm[int(so[u]):int(so[u + 1])].cpu().numpy()
+        np.testing.assert_allclose(out[int(fo[u]):int(fo[u + 1])], R.mfcc(y=y, **kw).T, rtol=0, atol=DB_TOL)
+    out2 = plan.execute(pcm * 0.5, d_so, d_fo, int(fo[-1])).cpu().numpy()
+    shift = 20 * np.log10(0.5) * np.sqrt(80.0)
+    np.testing.assert_allclose(out2[:, 0], out[:, 0] + shift, rtol=0, atol=5e-3)
+    np.testing.assert_allclose(out2[:, 1:], out[:, 1:], rtol=0, atol=5e-3)
