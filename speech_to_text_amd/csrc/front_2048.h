@@ -168,6 +168,14 @@ __device__ __forceinline__ void quad_fmac8(float* v, float s) {
     else MFCC_DPP_FMAC8("quad_perm:[1,0,3,2]");
 }
 
+// Lanes of bank group BANKS (bit g: lanes 4 g .. 4 g + 3 of every row of 16) take `src` from the
+// lane SHIFT below them in their row; the other lanes keep `old`.
+template <int SHIFT, int BANKS>
+__device__ __forceinline__ float dpp_row_shr(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                 0x110 + SHIFT, 0xF, BANKS, false));
+}
+
 // |X|^power from |X|^2.  PW = 0: power 2 (the reference's); PW = 1: any other power, decided at
 // run time (kept out of the power-2 instantiations: powf is ~200 instructions per call site).
 template <int PW>
@@ -554,11 +562,28 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         // All exchange reads of this wavefront are complete (data dependence above), so the
         // exchange region can be overwritten.  Column 0 goes to its scratch first so that its
         // round trip through LDS overlaps the regular power computation.
-        if (lane < 4) {
-            float2* S = reinterpret_cast<float2*>(X + SPECIAL_OFF) + kb * SPECIAL_ROW;
+        {
+            // Column 0's 64 outputs sit in lanes 0..3, 16 each.  An LDS write costs the same with 4
+            // active lanes as with 64, so they are first spread over lanes 0..15 with DPP row
+            // shifts -- lane 4 g + q takes outputs ka = 4 i + g of lane q -- and leave in four
+            // writes instead of sixteen.
+            float cr[4], ci[4];
 #pragma unroll
-            for (int ka = 0; ka < 16; ++ka)
-                S[ka] = make_float2(dr[fc::cfft16_pos(ka)], di[fc::cfft16_pos(ka)]);
+            for (int i = 0; i < 4; ++i) {
+                cr[i] = dr[fc::cfft16_pos(4 * i)];
+                ci[i] = di[fc::cfft16_pos(4 * i)];
+                cr[i] = dpp_row_shr<4, 0x2>(cr[i], dr[fc::cfft16_pos(4 * i + 1)]);
+                ci[i] = dpp_row_shr<4, 0x2>(ci[i], di[fc::cfft16_pos(4 * i + 1)]);
+                cr[i] = dpp_row_shr<8, 0x4>(cr[i], dr[fc::cfft16_pos(4 * i + 2)]);
+                ci[i] = dpp_row_shr<8, 0x4>(ci[i], di[fc::cfft16_pos(4 * i + 2)]);
+                cr[i] = dpp_row_shr<12, 0x8>(cr[i], dr[fc::cfft16_pos(4 * i + 3)]);
+                ci[i] = dpp_row_shr<12, 0x8>(ci[i], di[fc::cfft16_pos(4 * i + 3)]);
+            }
+            if (lane < 16) {
+                float2* S = reinterpret_cast<float2*>(X + SPECIAL_OFF) + kb * SPECIAL_ROW + k2c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) S[4 * i] = make_float2(cr[i], ci[i]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (lane >= 4) {

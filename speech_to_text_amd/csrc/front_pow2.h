@@ -175,6 +175,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
     const int pb1 = pbt + 2 * R * (4 - kb) - k2;
     const bool special = (k2 == 0);
     float2* s_wr = X2 + G::SCR_OFF / 2 + tf * (kp2::SPEC_STRIDE / 2) + kb;
+    // R == 4 (measured a gain there only): the row of 16 lanes whose first quad is a special slot writes that slot's outputs,
+    // lane 4 g + q of the row the outputs j = 4 (4 i + g) + kb, i = 0..3
+    const bool row_special = ((lane >> 4) * 4) % R == 0;
+    float2* s_wr4 = X2 + G::SCR_OFF / 2 + (((lane >> 4) * 4) / R) * (kp2::SPEC_STRIDE / 2) + 4 * ((lane >> 2) & 3) + kb;
     const int s_rd0 = G::SCR_OFF / 2 + lane, s_rd1 = G::SCR_OFF / 2 + ((64 - lane) & 63);
 
     float runmax = 0.0f;
@@ -301,7 +305,28 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
         // All exchange reads of this wavefront are complete (data dependence above), so the region
         // can be overwritten.  The special slots go to their scratch first so that their round trip
         // through LDS overlaps the regular power computation.
-        if (special) {
+        if (R == 4) {
+            // A special slot's 64 outputs sit in the first four lanes of a row of 16.  An LDS write
+            // costs the same with few active lanes as with 64, so they are first spread over the
+            // row with DPP row shifts -- lane 4 g + q of the row takes outputs ka = 4 i + g of lane
+            // q -- and leave in four writes instead of sixteen.
+            float cr[4], ci[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                cr[i] = dr[fc::cfft16_pos(4 * i)];
+                ci[i] = di[fc::cfft16_pos(4 * i)];
+                cr[i] = dpp_row_shr<4, 0x2>(cr[i], dr[fc::cfft16_pos(4 * i + 1)]);
+                ci[i] = dpp_row_shr<4, 0x2>(ci[i], di[fc::cfft16_pos(4 * i + 1)]);
+                cr[i] = dpp_row_shr<8, 0x4>(cr[i], dr[fc::cfft16_pos(4 * i + 2)]);
+                ci[i] = dpp_row_shr<8, 0x4>(ci[i], di[fc::cfft16_pos(4 * i + 2)]);
+                cr[i] = dpp_row_shr<12, 0x8>(cr[i], dr[fc::cfft16_pos(4 * i + 3)]);
+                ci[i] = dpp_row_shr<12, 0x8>(ci[i], di[fc::cfft16_pos(4 * i + 3)]);
+            }
+            if (row_special) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_wr4[16 * i] = make_float2(cr[i], ci[i]);
+            }
+        } else if (special) {
 #pragma unroll
             for (int ka = 0; ka < 16; ++ka)
                 s_wr[4 * ka] = make_float2(dr[fc::cfft16_pos(ka)], di[fc::cfft16_pos(ka)]);
