@@ -236,3 +236,48 @@ def test_packed_sink_int16_ingest_and_device_dataset(gpu, tmp_path):
         mf, sr, text, spk = ds[i]
         assert isinstance(mf, torch.Tensor) and mf.is_cuda and tuple(mf.shape) == ref[i].shape
         assert np.array_equal(mf.cpu().numpy(), ref[i]) and (sr, text, spk) == (16000, f"UTTERANCE {i}", 100 + i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(n_fft=2048, hop_length=512, n_mfcc=13),
+    dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
+])
+def test_execute_is_graph_capturable(gpu, kw):
+    """mfcc_execute launches its kernels on the caller's stream and neither allocates nor
+    synchronises, so a whole batch can be captured in a HIP graph and replayed on new audio."""
+    import torch
+
+    import speech_to_text_amd as S
+
+    dev = torch.device("cuda", 0)
+    plan = S.MfccPlan(S.make_config(**kw), dev)
+    ys = [speech_like(int(n), seed=80 + i) for i, n in enumerate(ragged_lengths(12, 0.3, 3.0, seed=4))]
+    so = np.zeros(len(ys) + 1, dtype=np.int64)
+    np.cumsum([len(y) for y in ys], out=so[1:])
+    fo = plan.frame_offsets(so)
+    F = int(fo[-1])
+    pcm = torch.from_numpy(np.concatenate(ys)).to(dev)
+    d_so, d_fo = torch.from_numpy(so).to(dev), torch.from_numpy(fo).to(dev)
+    out = torch.empty((F, kw["n_mfcc"]), dtype=torch.float32, device=dev)
+    ws = plan.workspace(F, len(ys))
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):                                  # eager reference (and warm-up)
+        plan.execute(pcm, d_so, d_fo, F, out=out, workspace=ws)
+    torch.cuda.synchronize()
+    eager = out.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        plan.execute(pcm, d_so, d_fo, F, out=out, workspace=ws)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    pcm.mul_(0.25)                                                  # new audio in the captured buffer
+    graph.replay()
+    torch.cuda.synchronize()
+    replayed = out.clone()
+    plan.execute(pcm, d_so, d_fo, F, out=out, workspace=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(out, replayed) and not torch.equal(replayed, eager)
+    plan.close()
