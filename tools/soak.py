@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Randomised soak of the front-end kernels: random configurations and ragged batches, each run
+twice (must be bit-identical) and cross-checked -- the in-register FFT kernels against the
+dense-DFT kernel (an independent implementation), the 2048-point kernel against the CPU oracle on
+one utterance of the batch.
+
+    python tools/soak.py [--seconds S] [--seed N]"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+import warnings
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import speech_to_text_amd as S  # noqa: E402
+from oracle import mfcc_ref as R  # noqa: E402
+
+
+def run(plan, pcm, so):
+    fo = plan.frame_offsets(so)
+    dev = pcm.device
+    out = plan.execute(pcm, torch.from_numpy(so).to(dev), torch.from_numpy(fo).to(dev), int(fo[-1]))
+    return out.cpu().numpy(), fo
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    warnings.simplefilter("ignore")
+    rng = np.random.default_rng(args.seed)
+    dev = torch.device("cuda", 0)
+    t_end = time.time() + args.seconds
+    n, worst, worst_kw = 0, 0.0, None
+    while time.time() < t_end:
+        n_fft = int(rng.choice([2048, 2048, 1024, 512, 400, 256]))
+        kw = dict(n_fft=n_fft, hop_length=int(rng.integers(n_fft // 8, n_fft + 1)), n_mels=int(rng.choice([20, 40, 64, 80, 128])),
+                  n_mfcc=int(rng.choice([13, 20])), sr=int(rng.choice([8000, 16000, 22050])),
+                  center=bool(rng.random() < 0.8), pad_mode=str(rng.choice(["constant", "reflect"])))
+        if rng.random() < 0.3:
+            kw["win_length"] = int(rng.integers(n_fft // 2, n_fft + 1))
+        cfg = S.make_config(**kw)
+        n_utts = int(rng.integers(1, 40))
+        lo = n_fft if not kw["center"] else 1
+        lens = [int(rng.integers(lo, lo + int(rng.choice([10, 3000, 60000])))) for _ in range(n_utts)]
+        ys = [(rng.standard_normal(L) * rng.choice([1e-3, 0.1, 1.0])).astype(np.float32) for L in lens]
+        if rng.random() < 0.3:
+            ys = [np.rint(np.clip(y, -0.99, 0.99) * 32767).astype(np.int16).astype(np.float32) / 32768.0 for y in ys]
+        so = np.zeros(n_utts + 1, dtype=np.int64)
+        np.cumsum(lens, out=so[1:])
+        pcm = torch.from_numpy(np.concatenate(ys)).to(dev)
+        os.environ.pop("MFCC_HIP_DENSE_DFT", None)
+        plan = S.MfccPlan(cfg, dev)
+        a, fo = run(plan, pcm, so)
+        b, _ = run(plan, pcm, so)
+        assert np.array_equal(a, b), f"not deterministic: {kw}"
+        assert np.isfinite(a).all(), f"non-finite output: {kw}"
+        if plan.front_kernel != "fft2048":
+            os.environ["MFCC_HIP_DENSE_DFT"] = "1"
+            dense = S.MfccPlan(cfg, dev)
+            os.environ.pop("MFCC_HIP_DENSE_DFT")
+            assert dense.front_kernel == "dense_dft"
+            c, _ = run(dense, pcm, so)
+            dense.close()
+            err = float(np.abs(a - c).max())
+        else:
+            u = int(rng.integers(0, n_utts))
+            want = R.mfcc(y=ys[u], **kw).T
+            err = float(np.abs(a[int(fo[u]):int(fo[u + 1])] - want).max())
+        assert err <= 1e-2, f"mismatch {err} dB: {kw}, lens {lens[:8]}..."
+        if err > worst:
+            worst, worst_kw = err, dict(kw, kernel=plan.front_kernel, scale=float(np.abs(ys[0]).max()))
+        plan.close()
+        n += 1
+    print(f"soak ok: {n} random batches, worst |diff| {worst:.2e} dB at {worst_kw}")
+
+
+if __name__ == "__main__":
+    main()
