@@ -186,25 +186,51 @@ constexpr float S25[25] = {
     -0.9048270524660198f, -0.98228725072868872f, -0.99802672842827156f, -0.95105651629515364f,
     -0.84432792550201496f, -0.68454710592868895f, -0.4817536741017161f, -0.24868988716485535f};
 
-// Real 25-point DFT, bins 0..12: Y[c] = sum_a x[a] exp(-2 pi i a c / 25).
+// Real 25-point DFT, bins 0..12: Y[c] = sum_a x[a] exp(-2 pi i a c / 25), as 5 x 5: with
+// a = 5 a1 + a2 and c = c1 + 5 c2,  W_25^(a c) = W_5^(a1 c1) W_25^(a2 c1) W_5^(a2 c2).
+//   step A  five real 5-point DFTs over a1 (bins c1 = 0, 1, 2; 3 and 4 are their conjugates)
+//   twiddle by W_25^(a2 c1)
+//   step B  five complex 5-point DFTs over a2, of which only the bins c <= 12 are formed
 FC_HD void rdft25(const float (&x)[25], float (&yr)[13], float (&yi)[13]) {
-    float e[13], o[13];
-    e[0] = x[0]; o[0] = 0.0f;
+    constexpr float c1 = 0.30901699437494745f, c2 = -0.80901699437494734f;   // cos 2 pi / 5, cos 4 pi / 5
+    constexpr float s1 = 0.95105651629515353f, s2 = 0.58778525229247325f;    // sin 2 pi / 5, sin 4 pi / 5
+    float ur[5][5], ui[5][5];                                                // [a2][c1]
 #pragma unroll
-    for (int a = 1; a <= 12; ++a) { e[a] = x[a] + x[25 - a]; o[a] = x[a] - x[25 - a]; }
-    float s = e[0];
+    for (int a2 = 0; a2 < 5; ++a2) {
+        const float v0 = x[a2], p1 = x[5 + a2] + x[20 + a2], p2 = x[10 + a2] + x[15 + a2];
+        const float q1 = x[5 + a2] - x[20 + a2], q2 = x[10 + a2] - x[15 + a2];
+        ur[a2][0] = v0 + p1 + p2;                   ui[a2][0] = 0.0f;
+        ur[a2][1] = fmaf(c2, p2, fmaf(c1, p1, v0)); ui[a2][1] = -fmaf(s2, q2, s1 * q1);
+        ur[a2][2] = fmaf(c1, p2, fmaf(c2, p1, v0)); ui[a2][2] = fmaf(s1, q2, -s2 * q1);
+        ur[a2][3] = ur[a2][2];                      ui[a2][3] = -ui[a2][2];
+        ur[a2][4] = ur[a2][1];                      ui[a2][4] = -ui[a2][1];
+    }
 #pragma unroll
-    for (int a = 1; a <= 12; ++a) s += e[a];
-    yr[0] = s; yi[0] = 0.0f;
+    for (int a2 = 1; a2 < 5; ++a2) {
 #pragma unroll
-    for (int c = 1; c <= 12; ++c) {
-        float re = e[0], im = 0.0f;
+        for (int k = 1; k < 5; ++k) cmul(ur[a2][k], ui[a2][k], C25[a2 * k], -S25[a2 * k]);
+    }
 #pragma unroll
-        for (int a = 1; a <= 12; ++a) {
-            re = fmaf(e[a], C25[(a * c) % 25], re);
-            im = fmaf(o[a], -S25[(a * c) % 25], im);
+    for (int k = 0; k < 5; ++k) {
+        const float v0r = ur[0][k], v0i = ui[0][k];
+        const float p1r = ur[1][k] + ur[4][k], p1i = ui[1][k] + ui[4][k];
+        const float p2r = ur[2][k] + ur[3][k], p2i = ui[2][k] + ui[3][k];
+        const float q1r = ur[1][k] - ur[4][k], q1i = ui[1][k] - ui[4][k];
+        const float q2r = ur[2][k] - ur[3][k], q2i = ui[2][k] - ui[3][k];
+        yr[k] = v0r + p1r + p2r;
+        yi[k] = v0i + p1i + p2i;
+        {   // bin k + 5: A - i B, A = v0 + c1 p1 + c2 p2, B = s1 q1 + s2 q2
+            const float ar = fmaf(c2, p2r, fmaf(c1, p1r, v0r)), ai = fmaf(c2, p2i, fmaf(c1, p1i, v0i));
+            const float br = fmaf(s2, q2r, s1 * q1r), bi = fmaf(s2, q2i, s1 * q1i);
+            yr[k + 5] = ar + bi;
+            yi[k + 5] = ai - br;
         }
-        yr[c] = re; yi[c] = im;
+        if (k <= 2) {   // bin k + 10: A = v0 + c2 p1 + c1 p2, B = s2 q1 - s1 q2
+            const float ar = fmaf(c1, p2r, fmaf(c2, p1r, v0r)), ai = fmaf(c1, p2i, fmaf(c2, p1i, v0i));
+            const float br = fmaf(-s1, q2r, s2 * q1r), bi = fmaf(-s1, q2i, s2 * q1i);
+            yr[k + 10] = ar + bi;
+            yi[k + 10] = ai - br;
+        }
     }
 }
 

@@ -10,8 +10,7 @@
 // Frame x[n], n = 16 a + b (a < 25, b < 16); bin k = c + 25 d (c < 25, d < 16):
 //     W_400^(n k) = W_25^(a c) W_400^(b c) W_16^(b d)
 //  step 1  lane (t = lane>>4, b = lane&15) holds the 25 samples a = 0..24 of frame t and computes
-//          the real 25-point DFT over a for c = 0..12 directly from the even / odd parts
-//          x[a] +- x[25-a] (288 fused multiply-adds with literal constants)
+//          the real 25-point DFT over a for c = 0..12 in registers (5 x 5, fc::rdft25)
 //  twiddle Z[b][c] = Y[b][c] W_400^(b c)
 //  exchange through LDS: column (t, c) = 16 complex, columns 36 floats apart (conflict-free
 //          16-byte reads)
