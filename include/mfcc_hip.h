@@ -175,6 +175,16 @@ int mfcc_cmvn_accumulate(const float* d_feats, int64_t n_rows, int32_t n_mfcc, d
 int mfcc_cmvn_apply(float* d_feats, int64_t n_rows, int32_t n_mfcc, const double* d_stats,
                     double eps, void* stream);
 
+/* ---- dB scaling of a spectrogram (the reference's display path) --------------------------- */
+/* librosa.power_to_db (amplitude = 0) or librosa.amplitude_to_db (amplitude = 1) of the n floats at
+ * d_in: 10 log10(max(amin, v)) - 10 log10(max(amin, ref)), clamped at (its maximum over the whole
+ * array - top_db) when top_db >= 0; v = |x| or, for amplitudes, x^2 with ref and amin squared.
+ * ref_is_max != 0 takes the array's maximum as the reference (librosa's ref=np.max).  d_out may
+ * equal d_in; d_workspace is 256 bytes of device memory.  Replaces
+ * librosa.amplitude_to_db(np.abs(stft)) at /root/reference/src/preprocess.py:113-114. */
+int mfcc_to_db(const float* d_in, int64_t n, int32_t amplitude, float ref, int32_t ref_is_max, float amin,
+               float top_db, float* d_out, void* d_workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -306,6 +306,37 @@ __global__ __launch_bounds__(256) void k_cmvn_apply(float* __restrict__ x, int64
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// power_to_db / amplitude_to_db on an arbitrary array (the spectrogram display path)
+// ------------------------------------------------------------------------------------------
+// Pass 1: maximum of the (squared, for amplitudes) values, as float bits (the values are >= 0).
+__global__ __launch_bounds__(256) void k_to_db_max(const float* __restrict__ x, int64_t n, int amplitude,
+                                                   uint32_t* __restrict__ gmax) {
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = fabsf(x[i]);
+        m = fmaxf(m, amplitude ? v * v : v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(gmax, __float_as_uint(m));
+}
+
+// Pass 2: 10 log10(max(amin, v)) - 10 log10(max(amin, ref)), clamped at (its maximum - top_db).
+// ref_is_max: the reference is the array's maximum (librosa's ref=np.max).
+__global__ __launch_bounds__(256) void k_to_db(const float* x, int64_t n, int amplitude, float ref, int ref_is_max,
+                                               float amin, float top_db, const uint32_t* __restrict__ gmax,
+                                               float* out) {   // out may be x
+    const float vmax = __uint_as_float(*gmax);
+    const float ref_db = 10.0f * log10f(fmaxf(amin, ref_is_max ? vmax : ref));
+    const float thr = top_db >= 0.0f ? 10.0f * log10f(fmaxf(amin, vmax)) - ref_db - top_db : -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = fabsf(x[i]);
+        if (amplitude) v *= v;
+        out[i] = fmaxf(10.0f * log10f(fmaxf(amin, v)) - ref_db, thr);
+    }
+}
+
 template <typename T>
 int upload(const std::vector<T>& h, T** d) {
     *d = nullptr;
@@ -1114,6 +1145,25 @@ int mfcc_cmvn_apply(float* d_feats, int64_t n_rows, int32_t n_mfcc, const double
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 4096));
     hipLaunchKernelGGL(k_cmvn_apply, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_feats,
                        n_rows, n_mfcc, d_stats, eps);
+    HIP_TRY(hipGetLastError());
+    return MFCC_OK;
+}
+
+int mfcc_to_db(const float* d_in, int64_t n, int32_t amplitude, float ref, int32_t ref_is_max, float amin,
+               float top_db, float* d_out, void* d_workspace, void* stream) {
+    if (n < 0) return fail(MFCC_E_INVALID, "negative size");
+    if (!(amin > 0.0f)) return fail(MFCC_E_INVALID, "amin must be strictly positive");
+    if (n == 0) return MFCC_OK;
+    if (!d_in || !d_out || !d_workspace) return fail(MFCC_E_INVALID, "NULL buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t* gmax = static_cast<uint32_t*>(d_workspace);
+    HIP_TRY(hipMemsetAsync(gmax, 0, sizeof(uint32_t), st));
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192));
+    // amplitudes: ref and amin enter squared (amplitude_to_db = power_to_db(S^2, ref^2, amin^2))
+    const float r = amplitude ? ref * ref : fabsf(ref), am = amplitude ? amin * amin : amin;
+    if (top_db >= 0.0f || ref_is_max)
+        hipLaunchKernelGGL(k_to_db_max, dim3(blocks), dim3(256), 0, st, d_in, n, amplitude, gmax);
+    hipLaunchKernelGGL(k_to_db, dim3(blocks), dim3(256), 0, st, d_in, n, amplitude, r, ref_is_max, am, top_db, gmax, d_out);
     HIP_TRY(hipGetLastError());
     return MFCC_OK;
 }

@@ -295,6 +295,44 @@ def spectrogram(*, y=None, n_fft=2048, hop_length=512, power=1.0, device=None, v
     return res.transpose(0, 2, 1).reshape(lead + (nb, F))
 
 
+def _to_db(S, amplitude: bool, ref, amin: float, top_db, device):
+    if amin <= 0:
+        raise ParameterError("amin must be strictly positive")
+    if top_db is not None and top_db < 0:
+        raise ParameterError("top_db must be non-negative")
+    ref_is_max = callable(ref)
+    if ref_is_max and ref is not np.max and getattr(ref, "__name__", "") not in ("max", "amax"):
+        raise NotImplementedError("the only callable reference supported is np.max")
+    dev = _device(device if device is not None else (S.device if isinstance(S, torch.Tensor) and S.is_cuda else None))
+    as_tensor = isinstance(S, torch.Tensor)
+    if not as_tensor and np.iscomplexobj(S):
+        warnings.warn("power_to_db was called on complex input so phase information will be discarded.",
+                      stacklevel=3)
+        S = np.abs(S)
+    x = (S if as_tensor else torch.from_numpy(np.ascontiguousarray(S, dtype=np.float32))).to(device=dev, dtype=torch.float32)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    ws = torch.empty(256, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().mfcc_to_db(x.data_ptr(), x.numel(), 1 if amplitude else 0,
+                                         0.0 if ref_is_max else float(ref), 1 if ref_is_max else 0, float(amin),
+                                         -1.0 if top_db is None else float(top_db), out.data_ptr(), ws.data_ptr(),
+                                         torch.cuda.current_stream(dev).cuda_stream))
+    return out if as_tensor else out.cpu().numpy()
+
+
+def power_to_db(S, *, ref=1.0, amin=1e-10, top_db=80.0, device=None):
+    """``librosa.power_to_db``: ``10 log10(max(amin, S)) - 10 log10(max(amin, ref))``, clamped at the
+    array's maximum minus ``top_db``.  ``S``: numpy array or device tensor; same kind comes back."""
+    return _to_db(S, False, ref, amin, top_db, device)
+
+
+def amplitude_to_db(S, *, ref=1.0, amin=1e-5, top_db=80.0, device=None):
+    """``librosa.amplitude_to_db`` as the reference applies it to ``np.abs(stft)``
+    (/root/reference/src/preprocess.py:113-114): ``power_to_db(S**2, ref**2, amin**2)``."""
+    return _to_db(S, True, ref, amin, top_db, device)
+
+
 def mfcc_batch(ys: Sequence, *, sr=22050, n_mfcc=20, dct_type=2, norm="ortho", lifter=0, device=None,
                validate=True, return_tensor=False, int16_if_exact=False, **kwargs) -> List:
     """Ragged batch: ``ys`` is a sequence of mono utterances, each ``(T_i,)`` or ``(1, T_i)``

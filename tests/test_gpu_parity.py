@@ -273,3 +273,26 @@ def test_full_size_batch_properties_asr_front_ends(S, kw):
     shift = 20 * np.log10(0.5) * np.sqrt(80.0)
     np.testing.assert_allclose(out2[:, 0], out[:, 0] + shift, rtol=0, atol=5e-3)
     np.testing.assert_allclose(out2[:, 1:], out[:, 1:], rtol=0, atol=5e-3)
+
+
+@pytest.mark.parametrize("ref,top_db", [(1.0, 80.0), (np.max, 80.0), (0.5, None), (np.max, 30.0)])
+def test_amplitude_and_power_to_db(S, ref, top_db):
+    """The spectrogram display path of /root/reference/src/preprocess.py:111-114:
+    amplitude_to_db(np.abs(stft)) and power_to_db against the oracle's restatement."""
+    y = speech_like(30000, seed=11)
+    mag = S.spectrogram(y=y, n_fft=2048, hop_length=512)               # power=1, as :113
+    want = R.amplitude_to_db(R.spectrogram(y=y, n_fft=2048, hop_length=512, power=1.0) if hasattr(R, "spectrogram")
+                             else np.abs(R.stft(y, n_fft=2048, hop_length=512)), ref=ref, top_db=top_db)
+    got = S.amplitude_to_db(mag, ref=ref, top_db=top_db)
+    assert got.shape == want.shape and got.dtype == np.float32
+    np.testing.assert_allclose(got, want, rtol=0, atol=DB_TOL)
+    powr = mag.astype(np.float64) ** 2
+    np.testing.assert_allclose(S.power_to_db(powr.astype(np.float32), ref=ref, top_db=top_db),
+                               R.power_to_db(powr, ref=ref, top_db=top_db), rtol=0, atol=DB_TOL)
+    import torch
+
+    dev_in = torch.from_numpy(mag).cuda()
+    dev_out = S.amplitude_to_db(dev_in, ref=ref, top_db=top_db)
+    assert dev_out.is_cuda and np.array_equal(dev_out.cpu().numpy(), got)
+    with pytest.raises(S.ParameterError):
+        S.power_to_db(mag, amin=0.0)
