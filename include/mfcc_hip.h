@@ -185,6 +185,16 @@ int mfcc_cmvn_apply(float* d_feats, int64_t n_rows, int32_t n_mfcc, const double
 int mfcc_to_db(const float* d_in, int64_t n, int32_t amplitude, float ref, int32_t ref_is_max, float amin,
                float top_db, float* d_out, void* d_workspace, void* stream);
 
+/* ---- delta features (extension; the reference trains on the plain MFCCs) ------------------ */
+/* librosa.feature.delta(data, width, order, axis=time, mode='interp') on the concatenated
+ * (total_frames, n_coef) features of a ragged batch, every utterance on its own: the order-th
+ * Savitzky-Golay derivative of a degree-`order` fit over `width` frames; frames within width/2 of
+ * an utterance's ends take the derivative of the polynomial fitted to its first / last `width`
+ * frames.  h_frame_offsets is the host copy of d_frame_offsets (the width check needs the lengths:
+ * an utterance shorter than `width` is an error, as in librosa).  d_out must not alias d_feats. */
+int mfcc_delta(const float* d_feats, const int64_t* d_frame_offsets, const int64_t* h_frame_offsets, int32_t n_utts,
+               int32_t n_coef, int32_t width, int32_t order, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

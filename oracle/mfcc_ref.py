@@ -325,3 +325,23 @@ def process_audio_features(samples, *, n_fft=2048, hop_length=512, n_mfcc=13, **
         samples = samples[None, :]
     m = mfcc(y=samples, n_fft=n_fft, hop_length=hop_length, n_mfcc=n_mfcc, **kwargs)
     return np.ascontiguousarray(m[0].T)
+
+
+# --------------------------------------------------------------------------------------------
+# librosa.feature.delta (not called by the reference; checks the delta extension)
+# --------------------------------------------------------------------------------------------
+def delta(data, *, width=9, order=1, axis=-1, mode="interp", **kwargs):
+    """librosa.feature.delta: scipy.signal.savgol_filter(data, width, deriv=order, polyorder=order,
+    axis=axis, mode=mode)."""
+    import scipy.signal
+
+    data = np.atleast_1d(data)
+    if mode == "interp" and width > data.shape[axis]:
+        raise ParameterError(f"when mode='interp', width={width} cannot exceed data.shape[axis]={data.shape[axis]}")
+    if width < 3 or np.mod(width, 2) != 1:
+        raise ParameterError("width must be an odd integer >= 3")
+    if order <= 0 or not isinstance(order, (int, np.integer)):
+        raise ParameterError("order must be a positive integer")
+    kwargs.pop("deriv", None)
+    kwargs.setdefault("polyorder", order)
+    return scipy.signal.savgol_filter(data, width, deriv=order, axis=axis, mode=mode, **kwargs)

@@ -337,6 +337,40 @@ __global__ __launch_bounds__(256) void k_to_db(const float* x, int64_t n, int am
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Delta features (extension): Savitzky-Golay derivative along time, per utterance
+// ------------------------------------------------------------------------------------------
+constexpr int DELTA_MAX_WIDTH = 65;
+struct DeltaArgs {
+    const float* x;              // (rows, n_coef)
+    const int64_t* frame_off;    // (n_utts + 1)
+    float* out;                  // (rows, n_coef)
+    int64_t rows;
+    int32_t n_utts, n_coef, half;
+    float c[DELTA_MAX_WIDTH];    // c[k + half] multiplies x[t + k]
+};
+
+// librosa.feature.delta(mode='interp'): the polynomial fitted to the first / last `width` frames
+// has a constant derivative of the fitted order, so a frame closer than `half` to an end of its
+// utterance takes the value of the nearest frame that has a full window.
+__global__ __launch_bounds__(256) void k_delta(const DeltaArgs a) {
+    const int64_t total = a.rows * a.n_coef;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / a.n_coef;
+        const int c = (int)(i - row * a.n_coef);
+        int lo = 0, hi = a.n_utts;                 // utterance u: frame_off[u] <= row < frame_off[u + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.frame_off[mid] <= row) lo = mid; else hi = mid;
+        }
+        const int64_t f0 = a.frame_off[lo], f1 = a.frame_off[lo + 1];
+        const int64_t t = min(max(row, f0 + a.half), f1 - 1 - a.half);
+        float acc = 0.0f;
+        for (int k = -a.half; k <= a.half; ++k) acc = fmaf(a.c[k + a.half], a.x[(t + k) * a.n_coef + c], acc);
+        a.out[i] = acc;
+    }
+}
+
 template <typename T>
 int upload(const std::vector<T>& h, T** d) {
     *d = nullptr;
@@ -1164,6 +1198,68 @@ int mfcc_to_db(const float* d_in, int64_t n, int32_t amplitude, float ref, int32
     if (top_db >= 0.0f || ref_is_max)
         hipLaunchKernelGGL(k_to_db_max, dim3(blocks), dim3(256), 0, st, d_in, n, amplitude, gmax);
     hipLaunchKernelGGL(k_to_db, dim3(blocks), dim3(256), 0, st, d_in, n, amplitude, r, ref_is_max, am, top_db, gmax, d_out);
+    HIP_TRY(hipGetLastError());
+    return MFCC_OK;
+}
+
+int mfcc_delta(const float* d_feats, const int64_t* d_frame_offsets, const int64_t* h_frame_offsets, int32_t n_utts,
+               int32_t n_coef, int32_t width, int32_t order, float* d_out, void* stream) {
+    if (n_utts < 0 || n_coef < 1) return fail(MFCC_E_INVALID, "bad delta shape");
+    if (width < 3 || width % 2 == 0 || width > DELTA_MAX_WIDTH)
+        return fail(MFCC_E_INVALID, "width must be an odd integer >= 3 (and at most 65)");
+    if (order < 1 || order >= width) return fail(MFCC_E_INVALID, "order must be a positive integer below width");
+    if (n_utts == 0) return MFCC_OK;
+    if (!d_feats || !d_frame_offsets || !h_frame_offsets || !d_out) return fail(MFCC_E_INVALID, "NULL delta buffer");
+    for (int u = 0; u < n_utts; ++u) {
+        const int64_t F = h_frame_offsets[u + 1] - h_frame_offsets[u];
+        if (F > 0 && F < width)
+            return fail(MFCC_E_INVALID, "when mode='interp', width=" + std::to_string(width) +
+                                            " cannot exceed the " + std::to_string(F) + " frames of utterance " +
+                                            std::to_string(u));
+    }
+    // Savitzky-Golay coefficients of the order-th derivative of a degree-`order` least-squares fit:
+    // with A[k][j] = k^j (k = -half .. half), c = order! * (row `order` of (A^T A)^-1 A^T)
+    DeltaArgs a;
+    a.half = width / 2;
+    const int m = order + 1;
+    std::vector<double> N((size_t)m * m, 0.0), inv((size_t)m * m, 0.0);
+    for (int k = -a.half; k <= a.half; ++k)
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < m; ++j) N[(size_t)i * m + j] += std::pow((double)k, i + j);
+    for (int i = 0; i < m; ++i) inv[(size_t)i * m + i] = 1.0;
+    for (int col = 0; col < m; ++col) {                     // Gauss-Jordan with partial pivoting
+        int piv = col;
+        for (int r2 = col + 1; r2 < m; ++r2)
+            if (std::fabs(N[(size_t)r2 * m + col]) > std::fabs(N[(size_t)piv * m + col])) piv = r2;
+        for (int j = 0; j < m; ++j) {
+            std::swap(N[(size_t)col * m + j], N[(size_t)piv * m + j]);
+            std::swap(inv[(size_t)col * m + j], inv[(size_t)piv * m + j]);
+        }
+        const double d = N[(size_t)col * m + col];
+        if (std::fabs(d) < 1e-300) return fail(MFCC_E_INVALID, "order too large for this width");
+        for (int j = 0; j < m; ++j) { N[(size_t)col * m + j] /= d; inv[(size_t)col * m + j] /= d; }
+        for (int r2 = 0; r2 < m; ++r2) {
+            if (r2 == col) continue;
+            const double f = N[(size_t)r2 * m + col];
+            for (int j = 0; j < m; ++j) {
+                N[(size_t)r2 * m + j] -= f * N[(size_t)col * m + j];
+                inv[(size_t)r2 * m + j] -= f * inv[(size_t)col * m + j];
+            }
+        }
+    }
+    double fact = 1.0;
+    for (int i = 2; i <= order; ++i) fact *= i;
+    for (int k = -a.half; k <= a.half; ++k) {
+        double v = 0.0;
+        for (int j = 0; j < m; ++j) v += inv[(size_t)order * m + j] * std::pow((double)k, j);
+        a.c[k + a.half] = (float)(fact * v);
+    }
+    a.x = d_feats; a.frame_off = d_frame_offsets; a.out = d_out;
+    a.rows = h_frame_offsets[n_utts]; a.n_utts = n_utts; a.n_coef = n_coef;
+    if (a.rows == 0) return MFCC_OK;
+    const int64_t total = a.rows * n_coef;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 8192));
+    hipLaunchKernelGGL(k_delta, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return MFCC_OK;
 }

@@ -333,6 +333,38 @@ def amplitude_to_db(S, *, ref=1.0, amin=1e-5, top_db=80.0, device=None):
     return _to_db(S, True, ref, amin, top_db, device)
 
 
+def delta_batch(feats: torch.Tensor, frame_offsets, *, width: int = 9, order: int = 1) -> torch.Tensor:
+    """Delta features of a ragged batch: ``feats`` is the concatenated ``(total_frames, n_coef)``
+    device tensor ``MfccPlan.execute`` returns, ``frame_offsets`` its host offsets.  Every
+    utterance is differentiated on its own, as ``librosa.feature.delta(m, width=width, order=order,
+    mode='interp')`` would on its ``(n_coef, F)`` array.  (An extension: the reference trains on
+    the plain MFCCs.)"""
+    fo = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+    assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous() and feats.ndim == 2
+    assert int(fo[-1]) == feats.shape[0]
+    out = torch.empty_like(feats)
+    d_fo = torch.from_numpy(fo).to(feats.device)
+    with torch.cuda.device(feats.device):
+        rc = _lib.lib().mfcc_delta(feats.data_ptr(), d_fo.data_ptr(), fo.ctypes.data_as(C.POINTER(C.c_int64)),
+                                   len(fo) - 1, feats.shape[1], int(width), int(order), out.data_ptr(),
+                                   torch.cuda.current_stream(feats.device).cuda_stream)
+    if rc == _lib.MFCC_E_INVALID:
+        raise ParameterError(_lib.last_error())
+    _lib.check(rc)
+    return out
+
+
+def delta(data, *, width: int = 9, order: int = 1, axis: int = -1, device=None):
+    """``librosa.feature.delta(data, width=9, order=1, axis=-1, mode='interp')`` for one array
+    (time along ``axis``); numpy in, numpy out."""
+    arr = np.moveaxis(np.asarray(data, dtype=np.float32), axis, 0)
+    F = arr.shape[0]
+    flat = np.ascontiguousarray(arr.reshape(F, -1))
+    dev = _device(device)
+    out = delta_batch(torch.from_numpy(flat).to(dev), np.array([0, F], dtype=np.int64), width=width, order=order)
+    return np.moveaxis(out.cpu().numpy().reshape(arr.shape), 0, axis)
+
+
 def mfcc_batch(ys: Sequence, *, sr=22050, n_mfcc=20, dct_type=2, norm="ortho", lifter=0, device=None,
                validate=True, return_tensor=False, int16_if_exact=False, **kwargs) -> List:
     """Ragged batch: ``ys`` is a sequence of mono utterances, each ``(T_i,)`` or ``(1, T_i)``

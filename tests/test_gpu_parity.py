@@ -296,3 +296,29 @@ def test_amplitude_and_power_to_db(S, ref, top_db):
     assert dev_out.is_cuda and np.array_equal(dev_out.cpu().numpy(), got)
     with pytest.raises(S.ParameterError):
         S.power_to_db(mag, amin=0.0)
+
+
+@pytest.mark.parametrize("width,order", [(9, 1), (9, 2), (5, 1), (21, 3)])
+def test_delta_features(S, width, order):
+    """The delta extension against librosa.feature.delta's definition (scipy's savgol_filter in
+    the oracle), for one array and for a ragged batch whose utterances must not leak into each
+    other; an utterance shorter than the window is an error, as in librosa."""
+    import torch
+
+    ys = [speech_like(n, seed=60 + i) for i, n in enumerate([40000, 12000, 25000])]
+    feats = S.mfcc_batch(ys, n_fft=2048, hop_length=512, n_mfcc=13)
+    want = [R.delta(f.T.astype(np.float64), width=width, order=order).T for f in feats]
+    tol = 2e-4 * max(1.0, float(np.abs(np.concatenate(want)).max()))
+    got0 = S.delta(feats[0].T, width=width, order=order)                 # librosa layout (n_mfcc, F)
+    assert got0.shape == feats[0].T.shape and got0.dtype == np.float32
+    np.testing.assert_allclose(got0.T, want[0], rtol=0, atol=tol)
+    fo = np.zeros(len(feats) + 1, dtype=np.int64)
+    np.cumsum([f.shape[0] for f in feats], out=fo[1:])
+    dev = torch.from_numpy(np.concatenate(feats)).cuda()
+    out = S.delta_batch(dev, fo, width=width, order=order).cpu().numpy()
+    for u, w in enumerate(want):
+        np.testing.assert_allclose(out[int(fo[u]):int(fo[u + 1])], w, rtol=0, atol=tol)
+    with pytest.raises(S.ParameterError):
+        S.delta(feats[0].T[:, :width - 1], width=width, order=order)
+    with pytest.raises(S.ParameterError):
+        S.delta(feats[0].T, width=4)
