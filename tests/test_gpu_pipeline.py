@@ -281,3 +281,18 @@ def test_execute_is_graph_capturable(gpu, kw):
     torch.cuda.synchronize()
     assert torch.equal(out, replayed) and not torch.equal(replayed, eager)
     plan.close()
+
+
+@pytest.mark.gpu
+def test_random_configurations_cross_check(gpu):
+    """150 random configurations and ragged batches (tools/soak.py, fixed seed): every batch runs
+    twice bit-identically, the in-register FFT kernels agree with the dense-DFT kernel and the
+    2048-point kernel with the oracle."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import soak
+
+    n, worst, where = soak.soak(seconds=60.0, seed=12345, max_batches=150)
+    assert n == 150 and worst <= 1e-2, (n, worst, where)

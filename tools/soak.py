@@ -31,17 +31,14 @@ def run(plan, pcm, so):
     return out.cpu().numpy(), fo
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seconds", type=float, default=60.0)
-    ap.add_argument("--seed", type=int, default=0)
-    args = ap.parse_args()
+def soak(seconds: float, seed: int, max_batches: int = 0):
+    """Returns (batches run, worst difference in dB, configuration of the worst case)."""
     warnings.simplefilter("ignore")
-    rng = np.random.default_rng(args.seed)
+    rng = np.random.default_rng(seed)
     dev = torch.device("cuda", 0)
-    t_end = time.time() + args.seconds
+    t_end = time.time() + seconds
     n, worst, worst_kw = 0, 0.0, None
-    while time.time() < t_end:
+    while time.time() < t_end and not (max_batches and n >= max_batches):
         n_fft = int(rng.choice([2048, 2048, 1024, 512, 400, 256]))
         kw = dict(n_fft=n_fft, hop_length=int(rng.integers(n_fft // 8, n_fft + 1)), n_mels=int(rng.choice([20, 40, 64, 80, 128])),
                   n_mfcc=int(rng.choice([13, 20])), sr=int(rng.choice([8000, 16000, 22050])),
@@ -81,6 +78,15 @@ def main():
             worst, worst_kw = err, dict(kw, kernel=plan.front_kernel, scale=float(np.abs(ys[0]).max()))
         plan.close()
         n += 1
+    return n, worst, worst_kw
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    n, worst, worst_kw = soak(args.seconds, args.seed)
     print(f"soak ok: {n} random batches, worst |diff| {worst:.2e} dB at {worst_kw}")
 
 
