@@ -195,6 +195,13 @@ int mfcc_to_db(const float* d_in, int64_t n, int32_t amplitude, float ref, int32
 int mfcc_delta(const float* d_feats, const int64_t* d_frame_offsets, const int64_t* h_frame_offsets, int32_t n_utts,
                int32_t n_coef, int32_t width, int32_t order, float* d_out, void* stream);
 
+/* ---- host helper for the 16-bit ingest ----------------------------------------------------- */
+/* h_dst[i] = h_src[i] * 32768 as int16.  Returns 1 if every sample lies on the int16 grid (the
+ * product is an integer in [-32768, 32767]: what torchaudio yields for the 16-bit FLAC of
+ * /root/reference/src/preprocess.py:75), 0 if not (then h_dst is not to be used), negative on bad
+ * arguments.  Host memory only, no GPU work; thread-safe. */
+int mfcc_host_pcm16_from_float(const float* h_src, int64_t n, int16_t* h_dst);
+
 #ifdef __cplusplus
 }
 #endif

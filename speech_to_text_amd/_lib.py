@@ -97,6 +97,7 @@ SYMBOLS = {
                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfcc_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                              C.c_void_p, C.c_void_p]),
+    "mfcc_host_pcm16_from_float": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "mfcc_cmvn_accumulate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "mfcc_cmvn_apply": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_double,
                                   C.c_void_p]),

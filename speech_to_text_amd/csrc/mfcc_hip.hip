@@ -1264,4 +1264,19 @@ int mfcc_delta(const float* d_feats, const int64_t* d_frame_offsets, const int64
     return MFCC_OK;
 }
 
+int mfcc_host_pcm16_from_float(const float* h_src, int64_t n, int16_t* h_dst) {
+    if (n < 0 || (n > 0 && (!h_src || !h_dst))) return fail(MFCC_E_INVALID, "bad host buffers");
+    // Branch-free so that the host compiler vectorises it.  Adding and subtracting 1.5 * 2^23
+    // rounds to the nearest integer for |v| < 2^22; anything larger (or NaN) fails the range test.
+    int ok = 1;
+    for (int64_t i = 0; i < n; ++i) {
+        const float v = h_src[i] * 32768.0f;             // exact: a power of two
+        const float c = fminf(fmaxf(v, -32768.0f), 32767.0f);
+        const float r = (c + 12582912.0f) - 12582912.0f;
+        ok &= (r == v);
+        h_dst[i] = (int16_t)(int32_t)r;
+    }
+    return ok;
+}
+
 }  // extern "C"

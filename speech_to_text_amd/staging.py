@@ -25,6 +25,8 @@ from typing import List, Sequence, Tuple
 import numpy as np
 import torch
 
+from . import _lib
+
 CHUNK_BYTES = 64 << 20
 N_THREADS = max(1, min(8, (os.cpu_count() or 2) - 1))
 
@@ -63,12 +65,17 @@ def _pack_range(chans: List[np.ndarray], so: np.ndarray, dst: np.ndarray, c0: in
         src = chans[u][a - int(so[u]): e - int(so[u])]
         out = dst[a - c0: e - c0]
         if to_i16:
-            scaled = src * np.float32(32768.0)              # exact: a power of two
-            r = np.rint(scaled)
-            if not (np.array_equal(r, scaled) and (r.size == 0 or (r.min() >= -32768.0 and r.max() <= 32767.0))):
+            if src.dtype == np.float32 and src.flags.c_contiguous:
+                good = _lib.lib().mfcc_host_pcm16_from_float(src.ctypes.data, src.size, out.ctypes.data) == 1
+            else:
+                scaled = src * np.float32(32768.0)              # exact: a power of two
+                r = np.rint(scaled)
+                good = bool(np.array_equal(r, scaled) and (r.size == 0 or (r.min() >= -32768.0 and r.max() <= 32767.0)))
+                if good:
+                    np.copyto(out, r, casting="unsafe")
+            if not good:
                 ok = False
                 break
-            np.copyto(out, r, casting="unsafe")
         else:
             np.copyto(out, src)
         a = e
