@@ -1,3 +1,4 @@
+"""Time of staging.upload_ragged for one 120 MB batch in its three modes.  python tools/stage_time.py"""
 import sys, time, numpy as np, torch
 import os; sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 from speech_to_text_amd import staging
