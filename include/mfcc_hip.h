@@ -202,6 +202,21 @@ int mfcc_delta(const float* d_feats, const int64_t* d_frame_offsets, const int64
  * arguments.  Host memory only, no GPU work; thread-safe. */
 int mfcc_host_pcm16_from_float(const float* h_src, int64_t n, int16_t* h_dst);
 
+/* ---- host helper: the per-utterance feature file ------------------------------------------ */
+/* Writes a new HDF5 file holding one contiguous float32 dataset `dataset_name` of shape
+ * (rows, cols) with n_attrs scalar attributes: attribute i is named attr_names[i] and is the
+ * int64 attr_ints[i], or, where attr_is_string[i] != 0, the variable-length UTF-8 string
+ * attr_strings[i].  With dataset "mfccs" and the attributes speaker_id, chapter_id, utterance_id,
+ * sample_rate (ints) and transcript (string) this is the file of
+ * /root/reference/src/preprocess.py:138-144, readable by h5py as /root/reference/src/trainer.py:110-114
+ * reads it.  Host memory and file I/O only; thread-safe.  MFCC_OK or MFCC_E_INVALID
+ * (mfcc_host_file_error() tells why). */
+int mfcc_host_write_feature_file(const char* path, const char* dataset_name, const float* h_data, int64_t rows,
+                                 int64_t cols, int32_t n_attrs, const char* const* attr_names,
+                                 const int32_t* attr_is_string, const int64_t* attr_ints,
+                                 const char* const* attr_strings);
+const char* mfcc_host_file_error(void);
+
 #ifdef __cplusplus
 }
 #endif

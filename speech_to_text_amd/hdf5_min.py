@@ -231,6 +231,31 @@ def write_datasets(path, datasets) -> None:
             f.write(raw + b"\x00" * (-len(raw) % 8))
 
 
+def write_features_native(path, data: np.ndarray, attrs: Dict[str, AttrValue], name: str = "mfccs") -> None:
+    """write_features for a 2-D dataset through the native writer of libmfcc_hip.so
+    (mfcc_host_write_feature_file): the same bytes, without the interpreter -- and without its
+    lock, so files can be written from several threads at once."""
+    import ctypes as C
+
+    from . import _lib
+
+    arr = np.ascontiguousarray(data, dtype="<f4")
+    if arr.ndim != 2:
+        raise ValueError("the native writer takes 2-D datasets")
+    n = len(attrs)
+    names = (C.c_char_p * n)(*[k.encode("utf-8") for k in attrs])
+    is_str = (C.c_int32 * n)(*[1 if isinstance(v, str) else 0 for v in attrs.values()])
+    for k, v in attrs.items():
+        if not isinstance(v, str) and not (isinstance(v, (int, np.integer)) and not isinstance(v, bool)):
+            raise TypeError(f"attribute {k!r}: only int and str are supported, got {type(v).__name__}")
+    ints = (C.c_int64 * n)(*[0 if isinstance(v, str) else int(v) for v in attrs.values()])
+    strs = (C.c_char_p * n)(*[v.encode("utf-8") if isinstance(v, str) else None for v in attrs.values()])
+    rc = _lib.lib().mfcc_host_write_feature_file(str(path).encode("utf-8"), name.encode("utf-8"), arr.ctypes.data,
+                                                 arr.shape[0], arr.shape[1], n, names, is_str, ints, strs)
+    if rc != 0:
+        raise OSError(_lib.lib().mfcc_host_file_error().decode("utf-8", "replace"))
+
+
 def write_features(path, data: np.ndarray, attrs: Dict[str, AttrValue], name: str = "mfccs") -> None:
     """Write one dataset ``name`` (float32, C-contiguous, any rank >= 1) with scalar attributes
     (Python int -> int64, str -> variable-length UTF-8) to a new HDF5 file at ``path``."""

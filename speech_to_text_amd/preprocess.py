@@ -55,7 +55,8 @@ def feature_file_name(speaker_id, chapter_id, utterance_id) -> str:
 def write_feature_file(path, mfcc_frames: np.ndarray, *, speaker_id, chapter_id, utterance_id,
                        sample_rate, transcript, backend: Optional[str] = None) -> str:
     """Dataset ``mfccs`` + the five attributes of /root/reference/src/preprocess.py:139-144.
-    backend: 'h5py' (if importable), 'min' (the built-in writer) or None = h5py when available."""
+    backend: 'h5py' (if importable), 'native' (the writer inside libmfcc_hip.so), 'min' (the same
+    bytes from plain Python) or None = the first of these that is available."""
     attrs = dict(speaker_id=int(speaker_id), chapter_id=int(chapter_id), utterance_id=int(utterance_id),
                  sample_rate=int(sample_rate), transcript=str(transcript))
     if backend in (None, "h5py"):
@@ -69,6 +70,13 @@ def write_feature_file(path, mfcc_frames: np.ndarray, *, speaker_id, chapter_id,
             return "h5py"
         except ImportError:
             if backend == "h5py":
+                raise
+    if backend in (None, "native"):
+        try:
+            hdf5_min.write_features_native(path, mfcc_frames, attrs, name="mfccs")
+            return "native"
+        except ImportError:           # libmfcc_hip.so not built
+            if backend == "native":
                 raise
     hdf5_min.write_features(path, mfcc_frames, attrs, name="mfccs")
     return "min"
@@ -159,16 +167,10 @@ class Preprocessor:
         mine = lpt_shards(costs, self.world_size)[self.rank] if self.world_size > 1 else np.arange(len(items))
         sr = int(items[0][1]) if items else 16000
         batches = pack_batches(lengths[mine], int(self.max_batch_seconds * sr))
-        # the built-in writer holds the GIL (more threads only add hand-overs); h5py releases it
-        # around its file I/O
+        # One writer thread: per file the writers spend more time in the interpreter (arguments,
+        # byte strings) than in I/O, so more threads only add hand-overs of its lock -- measured
+        # slower with 4 threads than with 1 for all three backends.
         n_threads = 1
-        if multiprocess and self.hdf5_backend != "min":
-            try:
-                import h5py  # noqa: F401,WPS433
-
-                n_threads = max(1, min(4, (os.cpu_count() or 2) - 1))
-            except ImportError:
-                pass
         if verbose:
             print(f"Processing audio data... rank {self.rank}/{self.world_size}: {len(mine)} of {len(items)} "
                   f"utterances in {len(batches)} GPU batch(es), {n_threads} writer thread(s)")

@@ -2,6 +2,7 @@
 (with the oracle injected as the feature extractor)."""
 import shutil
 import subprocess
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -207,3 +208,36 @@ def test_hdf5_min_many_strings_span_collections(tmp_path):
     assert np.array_equal(ids, np.arange(70000)) and attrs == {"k": 3}
     with pytest.raises(ValueError):
         hdf5_min.write_datasets(tmp_path / "n.hdf5", [(f"d{i}", np.zeros(1, np.float32), None) for i in range(9)])
+
+
+def test_native_feature_file_writer_matches_python_writer(tmp_path):
+    """mfcc_host_write_feature_file (inside libmfcc_hip.so) writes byte for byte what hdf5_min's
+    Python writer does, for the reference's schema and the corner cases (no attributes, empty
+    dataset, non-ASCII and long strings); libhdf5's h5dump reads the result when it is installed."""
+    import shutil
+    import subprocess
+
+    from speech_to_text_amd import hdf5_min
+
+    rng = np.random.default_rng(5)
+    cases = [
+        (rng.random((700, 13), dtype=np.float32), dict(speaker_id=1089, chapter_id=134686, utterance_id=7,
+                                                       sample_rate=16000, transcript="HE HOPED THERE WOULD BE STEW")),
+        (rng.random((1, 13), dtype=np.float32), dict(transcript="ünïcödé ✓ text", speaker_id=-5)),
+        (np.zeros((0, 13), np.float32), dict(a=1)),
+        (rng.random((33, 7), dtype=np.float32), {}),
+        (rng.random((5, 3), dtype=np.float32), dict(t1="a", t2="", t3="x" * 5000, n=2 ** 40)),
+    ]
+    for i, (arr, attrs) in enumerate(cases):
+        a, b = tmp_path / f"py{i}.hdf5", tmp_path / f"native{i}.hdf5"
+        hdf5_min.write_features(a, arr, attrs)
+        hdf5_min.write_features_native(b, arr, attrs)
+        assert a.read_bytes() == b.read_bytes()
+        back, at = hdf5_min.read_features(b, "mfccs")
+        assert np.array_equal(back, arr) and at == attrs
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if Path("/opt/conda/bin/h5dump").exists() else None)
+    if h5dump:
+        out = subprocess.run([h5dump, "-H", str(tmp_path / "native0.hdf5")], capture_output=True, text=True)
+        assert out.returncode == 0 and "DATASET \"mfccs\"" in out.stdout and "transcript" in out.stdout
+    with pytest.raises(OSError):
+        hdf5_min.write_features_native(tmp_path / "no_such_dir" / "x.hdf5", cases[0][0], cases[0][1])
