@@ -215,6 +215,13 @@ int mfcc_host_write_feature_file(const char* path, const char* dataset_name, con
                                  int64_t cols, int32_t n_attrs, const char* const* attr_names,
                                  const int32_t* attr_is_string, const int64_t* attr_ints,
                                  const char* const* attr_strings);
+/* The same for n_files files in one call: file i gets h_data[i] (rows[i], cols) and the attribute
+ * values attr_ints / attr_strings [i * n_attrs .. i * n_attrs + n_attrs); names and kinds are shared.
+ * Stops at the first failure. */
+int mfcc_host_write_feature_files(int32_t n_files, const char* const* paths, const char* dataset_name,
+                                  const float* const* h_data, const int64_t* rows, int64_t cols, int32_t n_attrs,
+                                  const char* const* attr_names, const int32_t* attr_is_string,
+                                  const int64_t* attr_ints, const char* const* attr_strings);
 const char* mfcc_host_file_error(void);
 
 #ifdef __cplusplus

@@ -216,4 +216,21 @@ int mfcc_host_write_feature_file(const char* path, const char* dataset_name, con
     return MFCC_OK;
 }
 
+int mfcc_host_write_feature_files(int32_t n_files, const char* const* paths, const char* dataset_name,
+                                  const float* const* h_data, const int64_t* rows, int64_t cols, int32_t n_attrs,
+                                  const char* const* attr_names, const int32_t* attr_is_string,
+                                  const int64_t* attr_ints, const char* const* attr_strings) {
+    if (n_files < 0 || (n_files > 0 && (!paths || !h_data || !rows))) {
+        g_file_err = "bad arguments";
+        return MFCC_E_INVALID;
+    }
+    for (int32_t i = 0; i < n_files; ++i) {
+        const int rc = mfcc_host_write_feature_file(paths[i], dataset_name, h_data[i], rows[i], cols, n_attrs, attr_names,
+                                                    attr_is_string, attr_ints + (size_t)i * n_attrs,
+                                                    attr_strings + (size_t)i * n_attrs);
+        if (rc != MFCC_OK) return rc;
+    }
+    return MFCC_OK;
+}
+
 }  // extern "C"

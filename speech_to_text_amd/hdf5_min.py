@@ -256,6 +256,47 @@ def write_features_native(path, data: np.ndarray, attrs: Dict[str, AttrValue], n
         raise OSError(_lib.lib().mfcc_host_file_error().decode("utf-8", "replace"))
 
 
+def write_many_features_native(paths, arrays, attr_rows, name: str = "mfccs") -> None:
+    """One native call for many files: file i holds the 2-D float32 array ``arrays[i]`` with the
+    attributes ``attr_rows[i]`` (dicts with the same keys and value kinds for every file).  The
+    interpreter is only needed to line the arguments up; the files are written without it."""
+    import ctypes as C
+
+    from . import _lib
+
+    n = len(paths)
+    if n == 0:
+        return
+    keys = list(attr_rows[0].keys())
+    kinds = [isinstance(attr_rows[0][k], str) for k in keys]
+    arrs = [np.ascontiguousarray(a, dtype="<f4") for a in arrays]
+    cols = arrs[0].shape[1]
+    if any(a.ndim != 2 or a.shape[1] != cols for a in arrs):
+        raise ValueError("the native writer takes 2-D datasets of one width")
+    na = len(keys)
+    c_paths = (C.c_char_p * n)(*[str(p).encode("utf-8") for p in paths])
+    c_data = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    c_rows = (C.c_int64 * n)(*[a.shape[0] for a in arrs])
+    c_names = (C.c_char_p * na)(*[k.encode("utf-8") for k in keys])
+    c_kinds = (C.c_int32 * na)(*[1 if s else 0 for s in kinds])
+    ints, strs = [], []
+    for row in attr_rows:
+        if list(row.keys()) != keys:
+            raise ValueError("every file must carry the same attributes")
+        for k, is_str in zip(keys, kinds):
+            v = row[k]
+            if isinstance(v, str) != is_str:
+                raise TypeError(f"attribute {k!r} changes kind between files")
+            ints.append(0 if is_str else int(v))
+            strs.append(v.encode("utf-8") if is_str else None)
+    c_ints = (C.c_int64 * (n * na))(*ints)
+    c_strs = (C.c_char_p * (n * na))(*strs)
+    rc = _lib.lib().mfcc_host_write_feature_files(n, c_paths, name.encode("utf-8"), c_data, c_rows, cols, na, c_names,
+                                                  c_kinds, c_ints, c_strs)
+    if rc != 0:
+        raise OSError(_lib.lib().mfcc_host_file_error().decode("utf-8", "replace"))
+
+
 def write_features(path, data: np.ndarray, attrs: Dict[str, AttrValue], name: str = "mfccs") -> None:
     """Write one dataset ``name`` (float32, C-contiguous, any rank >= 1) with scalar attributes
     (Python int -> int64, str -> variable-length UTF-8) to a new HDF5 file at ``path``."""

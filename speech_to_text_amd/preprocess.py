@@ -142,6 +142,24 @@ class Preprocessor:
                            backend=self.hdf5_backend)
 
     def _write_many(self, pairs) -> None:
+        if self.hdf5_backend in (None, "native") and pairs:
+            use_native = self.hdf5_backend == "native"
+            if not use_native:
+                try:
+                    import h5py  # noqa: F401,WPS433
+                except ImportError:
+                    use_native = True
+            if use_native:
+                try:
+                    hdf5_min.write_many_features_native(
+                        [self.out_dir / feature_file_name(it[3], it[4], it[5]) for it, _ in pairs],
+                        [fr for _, fr in pairs],
+                        [dict(speaker_id=int(it[3]), chapter_id=int(it[4]), utterance_id=int(it[5]),
+                              sample_rate=int(it[1]), transcript=str(it[2])) for it, _ in pairs])
+                    return
+                except ImportError:           # libmfcc_hip.so not built
+                    if self.hdf5_backend == "native":
+                        raise
         for item, frames in pairs:
             self._write(item, frames)
 
