@@ -241,3 +241,14 @@ def test_native_feature_file_writer_matches_python_writer(tmp_path):
         assert out.returncode == 0 and "DATASET \"mfccs\"" in out.stdout and "transcript" in out.stdout
     with pytest.raises(OSError):
         hdf5_min.write_features_native(tmp_path / "no_such_dir" / "x.hdf5", cases[0][0], cases[0][1])
+    # many files in one call: the same bytes as one call per file
+    arrays = [rng.random((n, 13), dtype=np.float32) for n in (3, 0, 250)]
+    rows = [dict(speaker_id=10 + i, chapter_id=20, utterance_id=i, sample_rate=16000, transcript=f"TEXT {i} é")
+            for i in range(3)]
+    hdf5_min.write_many_features_native([tmp_path / f"many{i}.hdf5" for i in range(3)], arrays, rows)
+    for i in range(3):
+        hdf5_min.write_features(tmp_path / f"one{i}.hdf5", arrays[i], rows[i])
+        assert (tmp_path / f"many{i}.hdf5").read_bytes() == (tmp_path / f"one{i}.hdf5").read_bytes()
+    with pytest.raises(TypeError):
+        hdf5_min.write_many_features_native([tmp_path / "a.hdf5", tmp_path / "b.hdf5"], arrays[:2],
+                                            [dict(x=1), dict(x="s")])
