@@ -7,7 +7,7 @@ backend is nccl) of 2 * n_mfcc + 1 float64 sums.
 """
 from __future__ import annotations
 
-from typing import Optional
+
 
 import numpy as np
 import torch

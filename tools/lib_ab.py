@@ -4,7 +4,7 @@ events) of each library for one configuration, every library in a fresh child pr
 list repeated so that drift between runs shows.
 
     python tools/lib_ab.py <ref|asr512|asr400|fft1024> <hours> lib1.so [lib2.so ...]"""
-import json
+
 import os
 import subprocess
 import sys

@@ -2,7 +2,7 @@
 """Dense-DFT kernel time for each tiles-per-workgroup setting (MFCC_HIP_GENERIC_NT), one child
 process per setting so every plan is built fresh.  python tools/nt_sweep.py [--hours H]"""
 import argparse
-import json
+
 import os
 import subprocess
 import sys

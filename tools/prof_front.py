@@ -1,7 +1,7 @@
 """Runs the pipeline a few times on a small batch; meant to be run under rocprofv3 --pmc.
 
     python tools/prof_front.py [hours] [iterations] [ref|asr512|asr400|fft1024]"""
-import os, sys
+import sys
 from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
