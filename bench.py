@@ -9,6 +9,10 @@ N>1: every rank processes its own 10-hour shard (independent utterances, no coll
 data path) -> weak scaling; value = all ranks' audio-hours / max-over-ranks time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--hours H]
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its N ranks itself (one
+fresh child process per GPU, before this process has touched the GPU) and relays rank 0's line;
+under torch.distributed.run (WORLD_SIZE set) every rank runs main() directly.
 """
 from __future__ import annotations
 
@@ -28,6 +32,52 @@ sys.path.insert(0, str(ROOT))
 SR = 16000
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
 FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def csrc_sha256() -> str:
+    """Hash of the kernel sources: a committed counter profile is only quoted for the library it
+    was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = ROOT / "speech_to_text_amd" / "csrc"
+    for f in sorted(csrc.iterdir()):
+        if f.suffix in (".hip", ".h", ".cpp") or f.name == "Makefile":
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Starts n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one
+    GPU each), waits for all of them, prints rank 0's JSON line and returns non-zero if any rank
+    failed.  The parent never initialises the GPU and never replaces itself."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if any(codes) or line is None:
+        print(f"bench.py: rank exit codes {codes}" + ("" if line else ", no result line from rank 0"), file=sys.stderr)
+        return max([c for c in codes if c] + [1])
+    print(line)
+    return 0
 
 
 def make_batch(hours: float, seed: int, device, lo_s=2.0, hi_s=35.0):
@@ -153,26 +203,66 @@ def pcie_inclusive(plan, pcm, d_so, d_fo, total_frames, out, ws, total_samples):
                       "note": "16-bit PCM upload + mfcc_execute_pcm16"}}
 
 
+def stub_main(args, world, rank):
+    """BENCH_STUB=1: the rank plumbing of main() with a sleep instead of the GPU step (gloo, CPU
+    only) -- lets the CPU test suite run the launcher end to end."""
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    hours = 0.001 * (rank + 1)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, hours], dtype=torch.float64)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        elapsed = max(float(q[0]) for q in parts)
+        hours = sum(float(q[1]) for q in parts)
+    if rank == 0:
+        print(json.dumps({"metric": "audio-hours of MFCC/sec", "value": hours / (elapsed / args.steps), "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "stub": True}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if os.environ.get("BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--hours", type=float, default=10.0, help="audio-hours per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: nothing in this process has touched the GPU yet (device_count does not)
+        stub = os.environ.get("BENCH_STUB") == "1"
+        if not rehearsal and not stub and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible "
+                             "(BENCH_REHEARSAL=1 shares them between the ranks over gloo: a dry run)")
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks "
-                         f"(WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("BENCH_STUB") == "1":
+        return stub_main(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
     # BENCH_REHEARSAL=1: several ranks share the GPUs that exist and talk over gloo -- a dry run of
     # the multi-rank code path on a one-GPU machine, not a measurement.
-    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -209,18 +299,23 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    front_ms, dct_ms = [], []
+    # The steps run back to back with no host synchronisation in between: per-step times come from
+    # events on the launch stream (torch's current stream, which plan.execute launches on) and the
+    # per-kernel times from the library's own event ring, both read after the loop.
+    plan.set_profiling(True)            # forget the warm-up's events
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         step()
-        a, b = plan.last_timings()      # HIP events on the launch stream; waits for this step
-        front_ms.append(a)
-        dct_ms.append(b)
+    marks[args.steps].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
+    front_ms, dct_ms = plan.timing_history(min(args.steps, 256))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -239,6 +334,10 @@ def main():
         # every PCM sample read once + every mel value written once.
         front = float(np.mean(front_ms))
         dctm = float(np.mean(dct_ms))
+
+        def spread(v):
+            return {"min": float(np.min(v)), "median": float(np.median(v)), "max": float(np.max(v)), "n": int(len(v))}
+
         alg_front = 4.0 * total_samples + 4.0 * config.n_mels * total_frames
         alg_e2e = 4.0 * total_samples + 4.0 * config.n_mfcc * total_frames
         achieved = alg_front / (front * 1e-3) / 1e9
@@ -246,12 +345,15 @@ def main():
         flops_frame = 2.5 * 2048 * 11 + 3 * 1025 + 2 * 2018
         # HBM bytes of the dominant kernel from the committed PMC passes (profiles/, made by
         # tools/pmc_traffic.sh on this same command); only quoted when the workload is the same.
-        traffic, traffic_src = None, None
+        traffic, traffic_src = None, "no counter profile of this library build and workload under profiles/"
+        src_hash = csrc_sha256()
         for cand in sorted((ROOT / "profiles").glob("*_pmc_traffic.json"), reverse=True):
             try:
                 prof = json.loads(cand.read_text())
                 bl = prof.get("bench_line_under_profiler") or {}
                 if bl.get("config", {}).get("frames_per_gpu") != total_frames:
+                    continue
+                if prof.get("csrc_sha256") != src_hash:      # measured on other kernel sources: stale
                     continue
                 for kname, kv in prof["kernels"].items():
                     if "k_melspec" in kname:
@@ -268,6 +370,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "step_ms": spread(step_ms),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -291,9 +394,12 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "kernel_ms": front,
+                "kernel_ms_spread": spread(front_ms),
+                "csrc_sha256": src_hash,
                 "algorithmic_bytes_per_launch": alg_front,
                 "end_to_end_GBps": alg_e2e / ((front + dctm) * 1e-3) / 1e9,
                 "db_dct_kernel_ms": dctm,
+                "db_dct_kernel_ms_spread": spread(dct_ms),
                 "fp32_valu_tflops": flops_frame * total_frames / (front * 1e-3) / 1e12,
                 "fp32_valu_peak_tflops": FP32_VALU_PEAK_TFLOPS,
             },

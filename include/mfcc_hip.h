@@ -125,7 +125,8 @@ size_t mfcc_workspace_bytes(const mfcc_plan* plan, int64_t total_frames, int32_t
  * d_out            (total_frames, n_mfcc) float32, row-major.
  * d_group          optional (n_utts) int32: utterances with the same value share one top_db
  *                  maximum (the channels of one multi-channel librosa call); NULL -> every
- *                  utterance is its own group.  Values must be in [0, n_utts).
+ *                  utterance is its own group.  Values must be in [0, n_utts); an utterance whose
+ *                  value is not gets a maximum of its own and mfcc_workspace_status reports it.
  * d_melspec_out    optional (total_frames, n_mels) float32: receives the mel power
  *                  spectrogram (librosa.feature.melspectrogram, transposed); NULL -> the
  *                  workspace holds it.
@@ -145,6 +146,13 @@ int mfcc_execute_pcm16(const mfcc_plan* plan, const int16_t* d_pcm16, const int6
                        int64_t total_frames, float* d_out, float* d_melspec_out, void* d_workspace,
                        size_t workspace_bytes, void* stream);
 
+/* Waits for `stream` and reports what the kernels of the last mfcc_execute* on this workspace
+ * found wrong with their device-side inputs: MFCC_E_INVALID if a d_group value lay outside
+ * [0, n_utts) (the kernels give such an utterance a maximum of its own instead of indexing out of
+ * bounds), else MFCC_OK.  Optional: for callers that cannot vouch for d_group.  No counterpart in
+ * the reference. */
+int mfcc_workspace_status(const void* d_workspace, void* stream);
+
 /* |STFT|^power only: d_spec_out is (total_frames, 1 + n_fft/2) float32 row-major, i.e.
  * np.abs(librosa.stft(y))**power transposed (/root/reference/src/preprocess.py:111-113). */
 int mfcc_execute_spectrogram(const mfcc_plan* plan, const float* d_pcm,
@@ -159,6 +167,12 @@ int mfcc_execute_spectrogram(const mfcc_plan* plan, const float* d_pcm,
  * profiling.  No counterpart in the reference (it has no timing code). */
 int mfcc_plan_set_profiling(mfcc_plan* plan, int enable);
 int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_dct);
+/* The plan keeps the events of its last 256 executes since profiling was last enabled (enabling it
+ * again forgets them).  Copies the durations of the most recent min(max_n, recorded, 256) executes,
+ * oldest first, into ms_front / ms_db_dct (either may be NULL) after waiting for the last of them;
+ * returns how many, or a negative MFCC_E_* code.  Lets a timing loop run its executes back to back
+ * and read the per-kernel times afterwards.  No counterpart in the reference. */
+int mfcc_plan_timing_history(const mfcc_plan* plan, int32_t max_n, float* ms_front, float* ms_db_dct);
 /* Name of the front-end kernel the plan runs: "fft2048" (the reference's n_fft,
  * /root/reference/src/preprocess.py:134), "fft256", "fft400", "fft512", "fft1024" (in-register FFTs for the
  * short transforms of 16 kHz front ends) or "dense_dft" (any other even n_fft: the DFT as an fp32 MFMA

@@ -205,9 +205,11 @@ def stft(y, *, n_fft=2048, hop_length=None, win_length=None, window="hann", cent
     elif not (isinstance(hop_length, (int, np.integer)) and hop_length > 0):
         raise ParameterError(f"hop_length={hop_length} must be a positive integer")
     valid_audio(y)
-    if pad_mode not in ("constant", "reflect", "edge", "symmetric", "wrap", "linear_ramp",
-                        "maximum", "mean", "median", "minimum", "empty"):
-        raise ParameterError(f"pad_mode='{pad_mode}' is not supported")
+    if pad_mode in ("wrap", "maximum", "mean", "median", "minimum"):
+        # librosa 0.10.1 rejects exactly these five numpy.pad modes in stft
+        raise ParameterError(f"pad_mode='{pad_mode}' is not supported by librosa.stft")
+    if pad_mode not in ("constant", "reflect", "edge", "symmetric", "linear_ramp", "empty"):
+        raise ParameterError(f"pad_mode='{pad_mode}' is not a numpy.pad mode")
 
     fft_window = get_window(window, win_length, fftbins=True)      # float64
     fft_window = pad_center(fft_window, size=n_fft)

@@ -87,11 +87,13 @@ SYMBOLS = {
     "mfcc_execute_pcm16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
+    "mfcc_workspace_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mfcc_execute_spectrogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                            C.c_size_t, C.c_void_p]),
     "mfcc_plan_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mfcc_plan_last_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mfcc_plan_timing_history": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mfcc_plan_front_kernel": (C.c_char_p, [C.c_void_p]),
     "mfcc_to_db": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_float,
                              C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -96,7 +96,8 @@ static_assert(sizeof(Tile) == 32, "Tile must be 32 bytes");
 
 struct WsHeader {
     int32_t n_tiles;
-    int32_t pad[63];
+    int32_t bad_groups;   // utterances whose top_db group id was outside [0, n_utts)
+    int32_t pad[62];
 };
 
 struct MelPass {

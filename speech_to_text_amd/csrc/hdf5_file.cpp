@@ -199,9 +199,13 @@ int mfcc_host_write_feature_file(const char* path, const char* dataset_name, con
         return MFCC_E_INVALID;
     }
 
-    FILE* fp = std::fopen(path, "wb");
+    // Written under a temporary name and renamed once complete: a reader that walks the directory
+    // (/root/reference/src/trainer.py:106-114) never sees a truncated feature file, whatever
+    // interrupts the writer.
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* fp = std::fopen(tmp.c_str(), "wb");
     if (!fp) {
-        g_file_err = std::string("cannot open ") + path;
+        g_file_err = std::string("cannot open ") + tmp;
         return MFCC_E_INVALID;
     }
     bool ok = std::fwrite(f.data(), 1, f.size(), fp) == f.size();
@@ -210,7 +214,13 @@ int mfcc_host_write_feature_file(const char* path, const char* dataset_name, con
     if (nbytes % 8) ok = ok && std::fwrite(pad, 1, 8 - nbytes % 8, fp) == 8 - nbytes % 8;
     ok = (std::fclose(fp) == 0) && ok;
     if (!ok) {
-        g_file_err = std::string("short write to ") + path;
+        std::remove(tmp.c_str());
+        g_file_err = std::string("short write to ") + tmp;
+        return MFCC_E_INVALID;
+    }
+    if (std::rename(tmp.c_str(), path) != 0) {
+        std::remove(tmp.c_str());
+        g_file_err = std::string("cannot rename ") + tmp + " to " + path;
         return MFCC_E_INVALID;
     }
     return MFCC_OK;

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(1024) void k_prepare_scan(const int64_t* __restrict
         for (int i = 0; i < 1024; ++i) { const int32_t v = part[i]; part[i] = run; run += v; }
         tile_off[n_utts] = run;
         hdr->n_tiles = run;
+        hdr->bad_groups = 0;
     }
     __syncthreads();
     int32_t run = part[tid];
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256) void k_prepare_tiles(const int64_t* __restrict
                                                        const int64_t* __restrict__ frame_off,
                                                        const int32_t* __restrict__ group,
                                                        const int32_t* __restrict__ tile_off,
-                                                       int n_utts, Tile* __restrict__ tiles) {
+                                                       int n_utts, Tile* __restrict__ tiles,
+                                                       WsHeader* __restrict__ hdr) {
     const int tile = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_tiles = tile_off[n_utts];
     if (tile >= n_tiles) return;
@@ -100,7 +102,14 @@ __global__ __launch_bounds__(256) void k_prepare_tiles(const int64_t* __restrict
     t.F = (int32_t)(frame_off[u + 1] - frame_off[u]);
     t.f0 = (tile - tile_off[u]) * TILE_FRAMES;
     t.row0 = frame_off[u] + t.f0;
-    t.grp = group ? group[u] : u;
+    // a group id indexes the running maxima: one outside [0, n_utts) is reported through the
+    // header (mfcc_workspace_status) and replaced by the utterance's own slot
+    int grp = group ? group[u] : u;
+    if ((unsigned)grp >= (unsigned)n_utts) {
+        if (tile == tile_off[u]) atomicAdd(&hdr->bad_groups, 1);
+        grp = u;
+    }
+    t.grp = grp;
     tiles[tile] = t;
 }
 
@@ -450,9 +459,14 @@ struct mfcc_plan {
     // generic (dense DFT) front end geometry
     int g_kpad = 0, g_lda = 0, g_ldp = 0, g_coltiles = 0, g_nt = 1;
     size_t g_lds_bytes = 0;
-    // optional per-kernel timing (mfcc_plan_set_profiling)
+    // optional per-kernel timing (mfcc_plan_set_profiling): a ring of event triples (before the
+    // front end, after it, after dB+DCT), one triple per execute, so that a caller can run many
+    // executes back to back and read all their times afterwards
     bool profiling = false;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // before front, after front, after dB+DCT
+    static constexpr int EV_RING = 256;
+    hipEvent_t (*ev_ring)[3] = nullptr;
+    mutable int64_t ev_count = 0;                    // executes recorded since profiling was (re)enabled
+    mutable hipEvent_t* ev = nullptr;                // the triple of the execute being recorded
 };
 
 namespace {
@@ -922,7 +936,11 @@ void mfcc_plan_destroy(mfcc_plan* p) {
     (void)hipFree(p->d_dct_frag);
     (void)hipFree(p->d_lifter); (void)hipFree(p->d_dfrag);
     (void)hipFree(p->d_p2_tw1); (void)hipFree(p->d_p2_melw); (void)hipFree(p->d_p2_pairs);
-    for (int i = 0; i < 3; ++i) if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
+    if (p->ev_ring) {
+        for (int i = 0; i < mfcc_plan::EV_RING; ++i)
+            for (int j = 0; j < 3; ++j) if (p->ev_ring[i][j]) (void)hipEventDestroy(p->ev_ring[i][j]);
+        delete[] p->ev_ring;
+    }
     delete p;
 }
 
@@ -939,12 +957,15 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     int32_t* tile_off = reinterpret_cast<int32_t*>(ws + L.tile_off);
     uint32_t* gmax = reinterpret_cast<uint32_t*>(ws + L.gmax);
     Tile* tiles = reinterpret_cast<Tile*>(ws + L.tiles);
+    if (pcm16 && plan->fast2048 && !plan->front.fn16)
+        return fail(MFCC_E_UNSUPPORTED, "this kernel variant has no int16 build (unset MFCC_HIP_VARIANT)");
+    if (plan->profiling) plan->ev = plan->ev_ring[plan->ev_count++ % mfcc_plan::EV_RING];
 
     hipLaunchKernelGGL(k_prepare_scan, dim3(1), dim3(1024), 0, st, d_frame_offsets, n_utts, tile_off,
                        gmax, hdr);
     const int pt_blocks = (int)((L.ub_tiles + 255) / 256);
     hipLaunchKernelGGL(k_prepare_tiles, dim3(pt_blocks), dim3(256), 0, st, d_sample_offsets,
-                       d_frame_offsets, d_group, tile_off, n_utts, tiles);
+                       d_frame_offsets, d_group, tile_off, n_utts, tiles, hdr);
 
     if (plan->small_fft) {
         Pow2Args pa;
@@ -1019,8 +1040,6 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     const int64_t wg_needed = (L.ub_tiles * TILE_FRAMES + fv.waves - 1) / fv.waves;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(wg_needed, plan->n_cu));
     if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
-    if (pcm16 && !fv.fn16)
-        return fail(MFCC_E_UNSUPPORTED, "this kernel variant has no int16 build (unset MFCC_HIP_VARIANT)");
     hipLaunchKernelGGL(pcm16 ? fv.fn16 : fv.fn, dim3(grid), dim3(fv.waves * 64), plan->front_lds_bytes, st, fa);
     if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[1], st));
     (void)total_frames;
@@ -1113,17 +1132,50 @@ int mfcc_execute_pcm16(const mfcc_plan* plan, const int16_t* d_pcm16, const int6
 
 int mfcc_plan_set_profiling(mfcc_plan* plan, int enable) {
     if (!plan) return fail(MFCC_E_INVALID, "plan is NULL");
-    if (enable && !plan->ev[0])
-        for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreate(&plan->ev[i]));
+    if (enable && !plan->ev_ring) {
+        plan->ev_ring = new (std::nothrow) hipEvent_t[mfcc_plan::EV_RING][3]();
+        if (!plan->ev_ring) return fail(MFCC_E_NOMEM, "out of host memory");
+        for (int i = 0; i < mfcc_plan::EV_RING; ++i)
+            for (int j = 0; j < 3; ++j) HIP_TRY(hipEventCreate(&plan->ev_ring[i][j]));
+    }
     plan->profiling = enable != 0;
+    plan->ev_count = 0;
+    plan->ev = nullptr;
     return MFCC_OK;
 }
 
 int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_dct) {
-    if (!plan || !plan->ev[0]) return fail(MFCC_E_INVALID, "profiling was not enabled on this plan");
-    HIP_TRY(hipEventSynchronize(plan->ev[2]));
-    if (ms_front) HIP_TRY(hipEventElapsedTime(ms_front, plan->ev[0], plan->ev[1]));
-    if (ms_db_dct) HIP_TRY(hipEventElapsedTime(ms_db_dct, plan->ev[1], plan->ev[2]));
+    if (!plan || !plan->ev_ring) return fail(MFCC_E_INVALID, "profiling was not enabled on this plan");
+    if (plan->ev_count == 0) return fail(MFCC_E_INVALID, "no execute has been recorded since profiling was enabled");
+    hipEvent_t* ev = plan->ev_ring[(plan->ev_count - 1) % mfcc_plan::EV_RING];
+    HIP_TRY(hipEventSynchronize(ev[2]));
+    if (ms_front) HIP_TRY(hipEventElapsedTime(ms_front, ev[0], ev[1]));
+    if (ms_db_dct) HIP_TRY(hipEventElapsedTime(ms_db_dct, ev[1], ev[2]));
+    return MFCC_OK;
+}
+
+int mfcc_plan_timing_history(const mfcc_plan* plan, int32_t max_n, float* ms_front, float* ms_db_dct) {
+    if (!plan || !plan->ev_ring) return fail(MFCC_E_INVALID, "profiling was not enabled on this plan");
+    if (max_n < 0) return fail(MFCC_E_INVALID, "max_n is negative");
+    const int64_t have = std::min<int64_t>(plan->ev_count, mfcc_plan::EV_RING);
+    const int n = (int)std::min<int64_t>(have, max_n);
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t* ev = plan->ev_ring[(plan->ev_count - n + i) % mfcc_plan::EV_RING];
+        HIP_TRY(hipEventSynchronize(ev[2]));
+        if (ms_front) HIP_TRY(hipEventElapsedTime(&ms_front[i], ev[0], ev[1]));
+        if (ms_db_dct) HIP_TRY(hipEventElapsedTime(&ms_db_dct[i], ev[1], ev[2]));
+    }
+    return n;
+}
+
+int mfcc_workspace_status(const void* d_workspace, void* stream) {
+    if (!d_workspace) return fail(MFCC_E_INVALID, "d_workspace is NULL");
+    WsHeader h;
+    HIP_TRY(hipMemcpyAsync(&h, d_workspace, sizeof(h), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (h.bad_groups != 0)
+        return fail(MFCC_E_INVALID, std::to_string(h.bad_groups) + " utterance(s) had a d_group value outside "
+                                    "[0, n_utts); each was given a top_db maximum of its own");
     return MFCC_OK;
 }
 
@@ -1150,9 +1202,10 @@ int mfcc_execute_spectrogram(const mfcc_plan* plan, const float* d_pcm,
         return fail(MFCC_E_WORKSPACE, "workspace too small: need " + std::to_string(L.total) + " bytes");
     if (reinterpret_cast<uintptr_t>(d_workspace) % 256)
         return fail(MFCC_E_INVALID, "workspace must be 256-byte aligned");
-    return launch_front(plan, d_pcm, false, d_sample_offsets, d_frame_offsets, nullptr, n_utts, total_frames,
-                        nullptr, d_spec_out, static_cast<char*>(d_workspace), L,
-                        static_cast<hipStream_t>(stream));
+    rc = launch_front(plan, d_pcm, false, d_sample_offsets, d_frame_offsets, nullptr, n_utts, total_frames,
+                      nullptr, d_spec_out, static_cast<char*>(d_workspace), L, static_cast<hipStream_t>(stream));
+    if (rc == MFCC_OK && plan->profiling) HIP_TRY(hipEventRecord(plan->ev[2], static_cast<hipStream_t>(stream)));
+    return rc;
 }
 
 int mfcc_cmvn_accumulate(const float* d_feats, int64_t n_rows, int32_t n_mfcc, double* d_stats,

@@ -9,6 +9,7 @@ PyTorch is used only for device memory and streams.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import threading
 import warnings
@@ -43,12 +44,16 @@ class MfccPlan:
         if rc == _lib.MFCC_E_INVALID:     # the cases librosa reports as ParameterError
             raise ParameterError(_lib.last_error())
         _lib.check(rc)
-        self._ws: Optional[torch.Tensor] = None
+        # one workspace per stream (include/mfcc_hip.h: a plan may be shared by several streams,
+        # each with its own workspace); a few streams at most are kept
+        self._ws: "collections.OrderedDict[int, torch.Tensor]" = collections.OrderedDict()
+        self._ws_lock = threading.Lock()
 
     def close(self):
         if self._handle:
             _lib.lib().mfcc_plan_destroy(self._handle)
             self._handle = C.c_void_p()
+            self._ws.clear()
 
     def __del__(self):
         try:
@@ -64,6 +69,16 @@ class MfccPlan:
         a, b = C.c_float(), C.c_float()
         _lib.check(_lib.lib().mfcc_plan_last_timings(self._handle, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def timing_history(self, max_n: int = 256):
+        """Per-kernel times (ms) of the most recent executes since profiling was enabled, oldest
+        first: two float32 arrays (front end, dB+DCT).  Waits for the last execute only."""
+        a = (C.c_float * max_n)()
+        b = (C.c_float * max_n)()
+        n = _lib.lib().mfcc_plan_timing_history(self._handle, int(max_n), a, b)
+        if n < 0:
+            _lib.check(n)
+        return np.array(a[:n], dtype=np.float32), np.array(b[:n], dtype=np.float32)
 
     @property
     def front_kernel(self) -> str:
@@ -87,12 +102,23 @@ class MfccPlan:
         _lib.check(rc)
         return fo
 
+    MAX_STREAM_WORKSPACES = 4
+
     def workspace(self, total_frames: int, n_utts: int) -> torch.Tensor:
+        """The workspace of the current stream, grown to fit the batch.  Executes on different
+        streams get different workspaces, so they may overlap; two threads that share one stream
+        must serialise their calls themselves (as for any stream-ordered buffer)."""
         need = int(_lib.lib().mfcc_workspace_bytes(self._handle, int(total_frames), int(n_utts)))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = int(torch.cuda.current_stream(self.device).cuda_stream)
+        with self._ws_lock:
+            ws = self._ws.pop(key, None)
+            if ws is None or ws.numel() < need:
+                ws = None
+                ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws                       # most recently used last
+            while len(self._ws) > self.MAX_STREAM_WORKSPACES:
+                self._ws.popitem(last=False)
+            return ws
 
     # ------------------------------------------------------------------------------------
     def execute(self, pcm: torch.Tensor, sample_offsets: torch.Tensor, frame_offsets: torch.Tensor,
@@ -133,20 +159,25 @@ class MfccPlan:
         return out
 
 
-_PLANS = {}
+_PLANS: "collections.OrderedDict" = collections.OrderedDict()
 _PLANS_LOCK = threading.Lock()
+MAX_CACHED_PLANS = 16
 
 
 def get_plan(config: MfccConfig, device=None) -> MfccPlan:
     """Plans are cached per (config, device): librosa rebuilds its filterbank on every call
-    (/root/reference/src/preprocess.py:134), this engine builds its tables once."""
+    (/root/reference/src/preprocess.py:134), this engine builds its tables once.  The cache keeps
+    the MAX_CACHED_PLANS most recently used plans; an evicted plan frees its device tables when
+    its last user drops it."""
     dev = _device(device)
     key = (config, dev.index)
     with _PLANS_LOCK:
-        plan = _PLANS.get(key)
+        plan = _PLANS.pop(key, None)
         if plan is None:
             plan = MfccPlan(config, dev)
-            _PLANS[key] = plan
+        _PLANS[key] = plan
+        while len(_PLANS) > MAX_CACHED_PLANS:
+            _PLANS.popitem(last=False)
         return plan
 
 
@@ -215,7 +246,12 @@ def _run_batch(chans: Sequence, config: MfccConfig, *, groups: Optional[np.ndarr
     if what == "spectrogram":
         out = plan.execute_spectrogram(pcm, d_so, d_fo, total_frames)
         return out, fo
-    d_grp = torch.from_numpy(np.ascontiguousarray(groups, dtype=np.int32)).to(plan.device) if groups is not None else None
+    d_grp = None
+    if groups is not None:
+        g = np.ascontiguousarray(groups, dtype=np.int32)
+        if g.shape != (len(chans),) or (len(g) and (g.min() < 0 or g.max() >= len(chans))):
+            raise ParameterError("groups must hold one value in [0, n_utterances) per utterance")
+        d_grp = torch.from_numpy(g).to(plan.device)
     if what == "melspectrogram":
         mel = torch.empty((total_frames, config.n_mels), dtype=torch.float32, device=plan.device)
         plan.execute(pcm, d_so, d_fo, total_frames, group=d_grp, melspec_out=mel)

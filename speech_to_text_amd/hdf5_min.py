@@ -17,6 +17,7 @@ strings in a global heap collection.
 """
 from __future__ import annotations
 
+import os
 import struct
 from typing import Dict, Tuple, Union
 
@@ -213,7 +214,10 @@ def write_datasets(path, datasets) -> None:
         snod += struct.pack("<QQI4x16x", off, ad, 0)
     snod += b"\x00" * (SNOD - len(snod))
 
-    with open(path, "wb") as f:
+    # written under a temporary name and renamed when complete: a directory walk never meets a
+    # truncated file
+    tmp = str(path) + ".tmp"
+    with open(tmp, "wb") as f:
         for part in (sb, root, btree, heap, heap_data, snod):
             f.write(part)
         for d, ad, (hdr, data_at, heap_at) in zip(prepared, a_data, headers):
@@ -229,6 +233,7 @@ def write_datasets(path, datasets) -> None:
             else:
                 raw = d["arr"].tobytes()
             f.write(raw + b"\x00" * (-len(raw) % 8))
+    os.replace(tmp, path)
 
 
 def write_features_native(path, data: np.ndarray, attrs: Dict[str, AttrValue], name: str = "mfccs") -> None:

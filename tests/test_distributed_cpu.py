@@ -80,3 +80,36 @@ def test_two_ranks_shard_and_allreduce(tmp_path):
     np.testing.assert_allclose(std, allf.std(0), rtol=1e-8)
     arr, attrs = read_feature_file(tmp_path / "mfcc" / "13_23_3.hdf5")
     assert attrs["transcript"] == "T3" and np.array_equal(arr, _extract([items[3][0]], n_fft=2048, hop_length=512, n_mfcc=13)[0])
+
+
+def _run_bench(args, extra_env):
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, str(root / "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=240)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no WORLD_SIZE) starts two fresh rank processes, relays rank 0's
+    single JSON line and aggregates over both ranks; BENCH_STUB=1 swaps the GPU step for a sleep so
+    that the launcher, the rendezvous and the max-over-ranks timing run on CPU (gloo)."""
+    import json
+
+    r = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1"], {"BENCH_STUB": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    r = _run_bench(["--gpus", "2", "--steps", "2"], {"BENCH_STUB": "1", "BENCH_STUB_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""          # no result line when a rank failed
+    assert "rank exit codes" in r.stderr

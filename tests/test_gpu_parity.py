@@ -19,12 +19,31 @@ MEL_RTOL = 1e-4        # relative, on mel power
 MEL_FLOOR = 2e-7       # x max mel power of the utterance
 
 
-def check_mel(got, want):
+def check_mel(got, want, amin=1e-10, top_db=80.0):
+    """Mel power against the oracle, two criteria, both asserted:
+    (1) <= 1e-4 relative, with the absolute floor an fp32 transform needs (its error scales with
+        the frame's energy, not with the band's);
+    (2) the log-mel criterion over the whole range top_db keeps: wherever the oracle's band lies
+        within top_db of the utterance's largest band, 10 log10 of the two values differ by
+        <= 1e-2 dB -- so the floor of (1) never hides an error that would survive into the
+        features.
+    Prints how many elements needed the floor and how far below the peak the highest of them sits."""
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
-    tol = MEL_RTOL * np.abs(want) + MEL_FLOOR * np.abs(want).max()
+    peak = np.abs(want).max()
     err = np.abs(got - want)
+    tol = MEL_RTOL * np.abs(want) + MEL_FLOOR * peak
     assert (err <= tol).all(), f"mel power: max err/tol = {(err / np.maximum(tol, 1e-300)).max():.3g}"
+    need_floor = err > MEL_RTOL * np.abs(want)
+    if need_floor.any() and peak > 0:
+        level = 10.0 * np.log10(np.maximum(want[need_floor], 1e-300) / peak)
+        print(f"check_mel: {int(need_floor.sum())} of {want.size} elements ({need_floor.mean():.2%}) exceed the "
+              f"relative bound alone; the highest sits {level.max():.1f} dB below the peak")
+    db_got = 10.0 * np.log10(np.maximum(amin, got))
+    db_want = 10.0 * np.log10(np.maximum(amin, want))
+    kept = db_want >= db_want.max() - top_db
+    worst = np.abs(db_got - db_want)[kept].max()
+    assert worst <= DB_TOL, f"log-mel within top_db of the peak differs by {worst:.3g} dB"
 
 
 @pytest.fixture(scope="module")
@@ -322,3 +341,90 @@ def test_delta_features(S, width, order):
         S.delta(feats[0].T[:, :width - 1], width=width, order=order)
     with pytest.raises(S.ParameterError):
         S.delta(feats[0].T, width=4)
+
+
+# ---- log-mel (power_to_db) itself, not only its first DCT coefficients ---------------------------
+def _idct_ortho(coefs, n_mels):
+    """Rows of an orthonormal DCT-II are an orthonormal basis: with all n_mels coefficients the
+    log-mel spectrogram is basis.T @ coefficients."""
+    k = np.arange(n_mels)[:, None]
+    n = np.arange(n_mels)[None, :]
+    basis = np.sqrt(2.0 / n_mels) * np.cos(np.pi * k * (2 * n + 1) / (2.0 * n_mels))
+    basis[0] *= np.sqrt(0.5)
+    return np.moveaxis(np.tensordot(basis.T, coefs.astype(np.float64), axes=([1], [-2])), 0, -2)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_fft=2048, hop_length=512, n_mels=128),                              # the reference's shape
+    dict(n_fft=2048, hop_length=512, n_mels=80),
+    dict(n_fft=2048, hop_length=512, n_mels=40, pad_mode="reflect"),
+    dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, sr=16000),      # BASELINE config 4
+    dict(n_fft=400, hop_length=160, n_mels=80, sr=16000),                      # BASELINE config 4, n_fft 400
+    dict(n_fft=1024, hop_length=256, n_mels=128),
+])
+@pytest.mark.parametrize("signal", ["speech", "quiet_tail", "two_channels"])
+def test_log_mel_parity(S, kw, signal):
+    """power_to_db with the per-call maximum and the top_db clamp, checked element by element:
+    with n_mfcc = n_mels the orthonormal DCT loses nothing, so the log-mel spectrogram is
+    recovered from the coefficients and compared with the oracle's
+    power_to_db(melspectrogram(y)) at 1e-2 dB (librosa.feature.mfcc at
+    /root/reference/src/preprocess.py:134 computes exactly that before its DCT)."""
+    n_mels = kw["n_mels"]
+    if signal == "speech":
+        y = speech_like(47001, seed=21)
+    elif signal == "quiet_tail":          # the second half sits on or near the top_db floor
+        y = speech_like(47001, seed=22)
+        y[24000:] *= np.float32(3e-5)
+    else:                                 # channels of one call share the maximum
+        y = np.stack([speech_like(30000, seed=23), speech_like(30000, seed=24) * np.float32(2e-4)])
+    want = R.power_to_db(R.melspectrogram(y=y, **kw))
+    got = _idct_ortho(S.mfcc(y=y, n_mfcc=n_mels, **kw), n_mels)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= DB_TOL, np.abs(got - want).max()
+    # the clamp is really exercised by the two stress signals
+    if signal != "speech":
+        assert (want <= want.max() - 80.0 + 1e-3).mean() > 0.05
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_fft=2048, hop_length=512, n_mels=128),
+    dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, sr=16000),
+    dict(n_fft=400, hop_length=160, n_mels=40, sr=16000),
+])
+def test_small_db_dct_kernel_matches_general_kernel(S, kw):
+    """<= 16 coefficients run the register-resident dB+DCT kernel, more run the general one
+    (whose log-mel test_log_mel_parity checks element by element).  Both start from the same mel
+    power, so their common coefficients may differ only by float32 rounding: 1e-3 dB here.  The
+    first basis row weighs every band by 1 / sqrt(n_mels), so an error in any single log-mel
+    element of the small kernel above ~1e-2 dB would show."""
+    y = speech_like(47001, seed=25)
+    y[30000:] *= np.float32(1e-4)
+    for dct_type in (2, 3):
+        small = S.mfcc(y=y, n_mfcc=16, dct_type=dct_type, **kw)
+        full = S.mfcc(y=y, n_mfcc=kw["n_mels"], dct_type=dct_type, **kw)
+        np.testing.assert_allclose(small, full[:16], rtol=0, atol=1e-3)
+
+
+def test_config5_long_utterances(S):
+    """BASELINE config 5: utterances of 30-60 s (938-1876 frames each, many tiles per utterance,
+    one top_db maximum across all of them), n_fft 2048, hop 512, 128 mels, top_db 80 -- plus one
+    45 s utterance that is noise at the 1e-5 level with a single full-scale click, so that
+    almost every band of it sits on the top_db floor set by one frame."""
+    rng = np.random.default_rng(5)
+    lens = (rng.uniform(30.0, 60.0, size=6) * SR).astype(np.int64)
+    ys = [speech_like(int(n), seed=500 + i) * np.float32(10.0 ** (-i / 3.0)) for i, n in enumerate(lens)]
+    click = (1e-5 * rng.standard_normal(45 * SR)).astype(np.float32)
+    click[17 * SR + 123] = 0.999
+    ys.insert(3, click)
+    feats = S.mfcc_batch(ys, n_fft=2048, hop_length=512, n_mfcc=13)
+    mels = S.mfcc_batch(ys, n_fft=2048, hop_length=512, n_mfcc=128)
+    for y, f, m in zip(ys, feats, mels):
+        want = R.process_audio_features(y)
+        assert f.shape == want.shape == (1 + len(y) // 512, 13)
+        np.testing.assert_allclose(f, want, rtol=0, atol=DB_TOL)
+        # and the log-mel itself, through the full DCT
+        logmel = _idct_ortho(m.T, 128)
+        want_db = R.power_to_db(R.melspectrogram(y=y, n_fft=2048, hop_length=512))
+        assert np.abs(logmel - want_db).max() <= DB_TOL
+    want_db = R.power_to_db(R.melspectrogram(y=click, n_fft=2048, hop_length=512))
+    assert (want_db <= want_db.max() - 80.0 + 1e-3).mean() > 0.9     # the click sets the floor

@@ -296,3 +296,70 @@ def test_random_configurations_cross_check(gpu):
 
     n, worst, where = soak.soak(seconds=60.0, seed=12345, max_batches=150)
     assert n == 150 and worst <= 1e-2, (n, worst, where)
+
+
+def test_out_of_range_group_is_reported_not_dereferenced(gpu):
+    """A d_group value outside [0, n_utts) must not index the per-utterance maxima: the kernels
+    give that utterance a maximum of its own and mfcc_workspace_status returns MFCC_E_INVALID."""
+    import torch
+
+    import speech_to_text_amd as S
+    from speech_to_text_amd import _lib
+
+    lib = _lib.lib()
+    plan = S.get_plan(S.MfccConfig.reference_default(), gpu)
+    ys = [speech_like(n, seed=70 + i) for i, n in enumerate([20000, 31000, 9000])]
+    so = np.concatenate([[0], np.cumsum([len(y) for y in ys])]).astype(np.int64)
+    fo = plan.frame_offsets(so)
+    F = int(fo[-1])
+    pcm = torch.from_numpy(np.concatenate(ys)).to(gpu)
+    d_so, d_fo = torch.from_numpy(so).to(gpu), torch.from_numpy(fo).to(gpu)
+    ws = plan.workspace(F, 3)
+    stream = torch.cuda.current_stream().cuda_stream
+    good = plan.execute(pcm, d_so, d_fo, F, workspace=ws).cpu().numpy()
+    assert lib.mfcc_workspace_status(ws.data_ptr(), stream) == _lib.MFCC_OK
+    bad = torch.tensor([0, 1 << 30, -5], dtype=torch.int32, device=gpu)
+    out = plan.execute(pcm, d_so, d_fo, F, group=bad, workspace=ws).cpu().numpy()
+    assert lib.mfcc_workspace_status(ws.data_ptr(), stream) == _lib.MFCC_E_INVALID
+    assert "d_group" in _lib.last_error()
+    assert np.array_equal(out, good)              # own maximum each == the default grouping
+    with pytest.raises(S.ParameterError):         # the Python layer checks its host copy first
+        from speech_to_text_amd.feature import _run_batch
+        _run_batch(ys, S.MfccConfig.reference_default(), groups=np.array([0, 7, 1]), device=gpu)
+
+
+def test_timing_history_and_per_stream_workspaces(gpu):
+    """The plan's event ring returns one (front, dB+DCT) pair per execute, oldest first, without a
+    host synchronisation between the executes; executes on two streams use two workspaces."""
+    import torch
+
+    import speech_to_text_amd as S
+
+    plan = S.MfccPlan(S.MfccConfig.reference_default(), gpu)
+    y = speech_like(200000, seed=3)
+    so = np.array([0, len(y)], dtype=np.int64)
+    fo = plan.frame_offsets(so)
+    pcm = torch.from_numpy(y).to(gpu)
+    d_so, d_fo = torch.from_numpy(so).to(gpu), torch.from_numpy(fo).to(gpu)
+    plan.set_profiling(True)
+    outs = [plan.execute(pcm, d_so, d_fo, int(fo[-1])) for _ in range(5)]
+    front, dct = plan.timing_history(3)
+    assert front.shape == dct.shape == (3,) and (front > 0).all() and (dct > 0).all()
+    front, dct = plan.timing_history()
+    assert len(front) == 5
+    a, b = plan.last_timings()
+    assert a == pytest.approx(float(front[-1])) and b == pytest.approx(float(dct[-1]))
+    plan.set_profiling(True)
+    assert len(plan.timing_history()[0]) == 0
+    plan.set_profiling(False)
+    ws_main = plan.workspace(int(fo[-1]), 1)
+    side = torch.cuda.Stream(device=gpu)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ws_side = plan.workspace(int(fo[-1]), 1)
+        other = plan.execute(pcm, d_so, d_fo, int(fo[-1]))
+    assert ws_side.data_ptr() != ws_main.data_ptr()
+    side.synchronize()
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, other) for o in outs)
+    plan.close()

@@ -39,7 +39,11 @@ if log.exists():
     for line in log.read_text().splitlines():
         if line.startswith("{") and '"metric"' in line:
             bench_line = json.loads(line)
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import csrc_sha256  # noqa: E402  (bench.py quotes this profile only for the same kernel sources)
+
 json.dump({"command": f"rocprofv3 ... -- {command} (one run per counter set)",
+           "csrc_sha256": csrc_sha256(),
            "kernels": summary, "kernel_stats": rows, "bench_line_under_profiler": bench_line},
           open(out / f"{tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: {"hbm_bytes": v["hbm_bytes"]} for k, v in summary.items()}, indent=1))
