@@ -49,6 +49,15 @@ __host__ __device__ constexpr int xch_slot(int k2, int c) {   // complex index o
 #ifndef MFCC_AB_QUAD_ASM
 #define MFCC_AB_QUAD_ASM 1
 #endif
+#ifndef MFCC_AB_WIN_PAIRS
+#define MFCC_AB_WIN_PAIRS 1
+#endif
+// Development only: compile-time removal of one piece of the frame loop (the results are then
+// garbage; only the kernel time is of interest).  1 mel stage, 2 sample loads, 4 window, 8 first
+// DFT-16 + split, 16 exchange, 32 quad DFT-4, 64 second DFT-16, 128 column-0 path, 256 power store
+#ifndef MFCC_ABL
+#define MFCC_ABL 0
+#endif
 constexpr int P_ROW_BINS = 64;
 constexpr int P_ROW = 80;
 constexpr int P_END = 16 * P_ROW + 16;            // bin 1024 sits at 1280; reads may run on to here
@@ -110,7 +119,9 @@ struct FrontArgs {
     const Tile* tiles;
     const WsHeader* hdr;
     const float* window;     // 2048
+    const float4* window_t;  // the window lane-major: float 32 lane + n2 = window[lane + 64 n2]
     const float2* tw1;       // 15 x 64, scaled
+    const float4* tw1_t;     // step-1 twiddles lane-major: complex 16 lane + k2 - 1, k2 = 1..15
     const float2* w64;       // 4 x 16
     const float2* tw128;     // 64
     const float4* melw;      // (n_jobs * MEL_J) x 64 quads of weights
@@ -254,9 +265,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* X = lds + wave * XCH_FLOATS;
-    float2* X2 = reinterpret_cast<float2*>(X);
-    float* tab = lds + WAVES * XCH_FLOATS;
+    // Tables first, per-wavefront regions after them: a DS instruction's immediate offset reaches
+    // 64 KB, so every table read addresses off one per-lane register (tables behind the 128 KB of
+    // regions needed a register per read: 15 for the step-1 twiddles alone).
+    float* tab = lds;
     float2* tw1_l = reinterpret_cast<float2*>(tab);
     if (TW1 == IN_LDS) tab += TW1_FLOATS;
     float2* w64_l = reinterpret_cast<float2*>(tab);
@@ -267,11 +279,35 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     int2* jobs_l = reinterpret_cast<int2*>(melw_l + a.n_jobs * MEL_J * 64);
     // one slot counter per group of wavefronts that share a run (after the tables)
     int* run_ctr = MELW_LDS ? reinterpret_cast<int*>(jobs_l + a.n_jobs * 64) : reinterpret_cast<int*>(melw_l);
+    float* regions = reinterpret_cast<float*>(run_ctr + 16);
+    float* X = regions + wave * XCH_FLOATS;
+    float2* X2 = reinterpret_cast<float2*>(X);
 
-    for (int i = tid; i < WAVES * XCH_FLOATS; i += THREADS) lds[i] = 0.0f;
+    for (int i = tid; i < WAVES * XCH_FLOATS; i += THREADS) regions[i] = 0.0f;
     if (TW1 == IN_LDS) { for (int i = tid; i < 15 * 64; i += THREADS) tw1_l[i] = a.tw1[i]; }
-    if (!W64_REGS) { if (tid < 64) w64_l[(tid >> 4) * W64_STRIDE + (tid & 15)] = a.w64[tid]; }
-    if (WIN == IN_LDS) { for (int i = tid; i < 2048; i += THREADS) win_l[i] = a.window[i]; }
+    // step-2 twiddles W_64^(m kb), m = 1..15, at slot m - 1 of row kb (m = 0 is 1 and never read):
+    // the eight 16-byte reads of a row then carry only values that are used, so the compiler
+    // keeps them as ds_read_b128
+    if (!W64_REGS) {
+        if (tid < 64) {
+            const int m = tid & 15;
+            w64_l[(tid >> 4) * W64_STRIDE + (m ? m - 1 : 15)] = m ? a.w64[tid] : make_float2(0.0f, 0.0f);
+        }
+    }
+    // window in LDS as quads: float4 (j, lane) = w[lane + 64 (4 j + c)], c = 0..3, so that a lane's
+    // 32 values come in 8 conflict-free ds_read_b128 (4 LDS cycles each; 32 ds_read_b32 take 2 each,
+    // and pairs of ds_read_b64 get merged into half-rate ds_read2st64_b64)
+    if (WIN == IN_LDS) {
+#if MFCC_AB_WIN_PAIRS
+        for (int i = tid; i < 512; i += THREADS) {
+            const int j = i >> 6, l = i & 63;
+            reinterpret_cast<float4*>(win_l)[i] = make_float4(a.window[l + 256 * j], a.window[l + 256 * j + 64],
+                                                              a.window[l + 256 * j + 128], a.window[l + 256 * j + 192]);
+        }
+#else
+        for (int i = tid; i < 2048; i += THREADS) win_l[i] = a.window[i];
+#endif
+    }
     if (tid < WAVES) run_ctr[tid] = 0;
     if (MELW_LDS) {
         for (int i = tid; i < a.n_jobs * MEL_J * 64; i += THREADS) melw_l[i] = a.melw[i];
@@ -459,17 +495,43 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
 #pragma unroll
                 for (int n2 = 0; n2 < 32; ++n2) src[n2] = PCM16_SCALE * (float)h[n2];
             } else if (HOPR == 0 || !raw_ok) {
+#if MFCC_ABL & 2
+#pragma unroll
+                for (int n2 = 0; n2 < 32; ++n2) src[n2] = (float)(lane + n2 + (int)row);
+#else
 #pragma unroll
                 for (int n2 = 0; n2 < 32; ++n2) src[n2] = pp[64 * n2];
+#endif
             }
-            if (WIN == IN_REGS) {
+            if (MFCC_ABL & 4) {
+#pragma unroll
+                for (int n2 = 0; n2 < 32; ++n2) r[n2] = src[n2];
+            } else if (WIN == IN_REGS) {
 #pragma unroll
                 for (int n2 = 0; n2 < 32; ++n2) r[n2] = src[n2] * win[n2];
             } else {
                 float wv[32];
+                if (WIN == IN_LDS) {
+#if MFCC_AB_WIN_PAIRS
+                    const float4* wq = reinterpret_cast<const float4*>(__builtin_assume_aligned(win_l, 16)) + lane;
 #pragma unroll
-                for (int n2 = 0; n2 < 32; ++n2)
-                    wv[n2] = (WIN == IN_LDS) ? win_l[lane + 64 * n2] : a.window[lane + 64 * n2];
+                    for (int j = 0; j < 8; ++j) {
+                        const float4 w4 = wq[64 * j];
+                        wv[4 * j] = w4.x; wv[4 * j + 1] = w4.y; wv[4 * j + 2] = w4.z; wv[4 * j + 3] = w4.w;
+                    }
+#else
+#pragma unroll
+                    for (int n2 = 0; n2 < 32; ++n2) wv[n2] = win_l[lane + 64 * n2];
+#endif
+                } else {
+                    // from global memory (the CU's vector cache): 8 loads of 16 bytes
+                    const float4* wt = a.window_t + 8 * lane;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float4 w4 = wt[j];
+                        wv[4 * j] = w4.x; wv[4 * j + 1] = w4.y; wv[4 * j + 2] = w4.z; wv[4 * j + 3] = w4.w;
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);   // all table reads in flight before the first use
 #pragma unroll
                 for (int n2 = 0; n2 < 32; ++n2) r[n2] = src[n2] * wv[n2];
@@ -489,19 +551,41 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         }
 
         // ---- step 1: real DFT-32 over n2, twiddle, exchange ------------------------------------
+#if MFCC_ABL & 16
+        float xkeep_r[16], xkeep_i[16];
+#endif
         {
             float zr[16], zi[16];
 #pragma unroll
             for (int m = 0; m < 16; ++m) { zr[m] = r[2 * m]; zi[m] = r[2 * m + 1]; }
-            fc::cfft16(zr, zi);
+            if (!(MFCC_ABL & 8)) fc::cfft16(zr, zi);
             __builtin_amdgcn_sched_barrier(0);
             float2 tw[16];
+            if (TW1 == IN_LDS) {
 #pragma unroll
-            for (int k2 = 1; k2 < 16; ++k2)
-                tw[k2] = (TW1 == IN_LDS) ? tw1_l[(k2 - 1) * 64 + lane] : a.tw1[(k2 - 1) * 64 + lane];
+                for (int k2 = 1; k2 < 16; ++k2) tw[k2] = tw1_l[(k2 - 1) * 64 + lane];
+            } else {
+                const float4* tt = a.tw1_t + 8 * lane;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 t4 = tt[j];
+                    tw[2 * j + 1] = make_float2(t4.x, t4.y);
+                    if (j < 7) tw[2 * j + 2] = make_float2(t4.z, t4.w);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);   // twiddle reads overlap the conjugate split
             float ar[16], ai[16];
-            fc::rdft32_split(zr, zi, ar, ai);
+            if (!(MFCC_ABL & 8)) fc::rdft32_split(zr, zi, ar, ai);
+            else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) { ar[m] = zr[m]; ai[m] = zi[m]; }
+            }
+#if MFCC_ABL & 16
+#pragma unroll
+            for (int k2 = 1; k2 < 16; ++k2) fc::cmul(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) { xkeep_r[k2] = ar[k2]; xkeep_i[k2] = ai[k2]; }
+#else
             X[y0_off] = ar[0];                   // y[n1]      = sum over even n2
             X[y1_off] = ai[0];                   // y[64 + n1] = sum over odd n2
 #pragma unroll
@@ -509,30 +593,41 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
                 fc::cmul(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
                 X2[k2 * COL_STRIDE + xw[k2 & 3]] = make_float2(ar[k2], ai[k2]);
             }
+#endif
         }
 
         // ---- step 2: quad DFT-4 (DPP), twiddle, DFT-16 over m -----------------------------------
         float dr[16], di[16];
         {
             float2 w6[16];
+#if MFCC_ABL & 16
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { dr[j] = xkeep_r[j]; di[j] = xkeep_i[j]; }
+#else
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float4 v = *reinterpret_cast<const float4*>(X + (xr_base ^ (4 * j)));
                 dr[2 * j] = v.x; di[2 * j] = v.y; dr[2 * j + 1] = v.z; di[2 * j + 1] = v.w;
             }
+#endif
             if (W64_REGS) {
 #pragma unroll
                 for (int m = 1; m < 16; ++m) w6[m] = w64r[m];
             } else {
-                const float4* wsrc = reinterpret_cast<const float4*>(w64_l + kb * W64_STRIDE);
+                // 16-byte aligned rows: one ds_read_b128 each (unaligned, the compiler splits them into
+                // ds_read2_b64, which run at half the rate)
+                const float4* wsrc = reinterpret_cast<const float4*>(
+                    __builtin_assume_aligned(reinterpret_cast<const char*>(w64_l) + kb * (W64_STRIDE * 8), 16));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float4 v = wsrc[j];
-                    w6[2 * j] = make_float2(v.x, v.y); w6[2 * j + 1] = make_float2(v.z, v.w);
+                    w6[2 * j + 1] = make_float2(v.x, v.y);
+                    if (j < 7) w6[2 * j + 2] = make_float2(v.z, v.w);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);   // all exchange + twiddle reads in flight
-#if MFCC_AB_QUAD_ASM
+#if MFCC_ABL & 32
+#elif MFCC_AB_QUAD_ASM
             quad_fmac8<2>(dr, sgn1); quad_fmac8<2>(dr + 8, sgn1);
             quad_fmac8<2>(di, sgn1); quad_fmac8<2>(di + 8, sgn1);
 #pragma unroll
@@ -556,7 +651,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
 #endif
 #pragma unroll
             for (int m = 1; m < 16; ++m) fc::cmul(dr[m], di[m], w6[m].x, w6[m].y);
-            fc::cfft16(dr, di);
+            if (!(MFCC_ABL & 64)) fc::cfft16(dr, di);
         }
 
         // ---- power spectrum -> LDS (natural bin order) -------------------------------------------
@@ -580,7 +675,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
                 cr[i] = dpp_row_shr<12, 0x8>(cr[i], dr[fc::cfft16_pos(4 * i + 3)]);
                 ci[i] = dpp_row_shr<12, 0x8>(ci[i], di[fc::cfft16_pos(4 * i + 3)]);
             }
-            if (lane < 16) {
+            if (lane < 16 && !(MFCC_ABL & 128)) {
                 float2* S = reinterpret_cast<float2*>(X + SPECIAL_OFF) + kb * SPECIAL_ROW + k2c;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) S[4 * i] = make_float2(cr[i], ci[i]);
@@ -592,7 +687,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             for (int ka = 0; ka < 16; ++ka) {
                 const float re = dr[fc::cfft16_pos(ka)], im = di[fc::cfft16_pos(ka)];
                 const float pw = apply_power<PW>(re * re + im * im, a.pw_mode, a.half_power);
-                if (ka < 8) X[pb0 + 2 * P_ROW * ka] = pw; else X[pb1 + 2 * P_ROW * (15 - ka)] = pw;
+                if (MFCC_ABL & 256) { if (pw == 12345.0f) X[pb0] = pw; }
+                else if (ka < 8) X[pb0 + 2 * P_ROW * ka] = pw; else X[pb1 + 2 * P_ROW * (15 - ka)] = pw;
             }
         }
         if (a.mel_out) {
@@ -601,10 +697,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         }
         // This lane's job descriptors are requested here so that they return while column 0
         // makes its round trip.
-        const bool mel_fast = MELW_LDS && n_jobs <= MEL_REG_JOBS && a.mel_out && !(a.ablate & 1);
+        const bool mel_fast = MELW_LDS && n_jobs <= MEL_REG_JOBS && a.mel_out && !(a.ablate & 1) && !(MFCC_ABL & 1);
         uint4 jq = make_uint4(0u, 0u, 0u, 0u);
         if (mel_fast) jq = reinterpret_cast<const uint4*>(jobs_l)[lane];
-        {
+        if (!(MFCC_ABL & 128)) {
             // column 0: C = DFT-64 of c[r] = y[2r] + i y[2r+1]; Y[j] = E[j] + W_128^j O[j]
             const float2* S = reinterpret_cast<const float2*>(X + SPECIAL_OFF);
             const float2 cj = S[sj];
@@ -635,7 +731,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         // outputs leave as coalesced rows.  (Filterbanks that would need more cell rows than
         // there are share one cell per filter through LDS atomics, which one wavefront executes
         // in program order, so that sum is deterministic too -- but slow.)
-        if (a.mel_out && !(a.ablate & 1)) {
+        if (a.mel_out && !(a.ablate & 1) && !(MFCC_ABL & 1)) {
             const int2* jp = (MELW_LDS ? jobs_l : a.mel_jobs) + lane;
             const float4* wp = (MELW_LDS ? melw_l : a.melw) + lane;
             char* Xb = reinterpret_cast<char*>(X);

@@ -21,6 +21,7 @@
 #include "../../include/mfcc_hip.h"
 #include "fft_core.h"
 #include "front_2048.h"
+#include "front_2048_fast.h"
 #include "front_generic.h"
 #include "front_pow2.h"
 #include "front_400.h"
@@ -431,6 +432,9 @@ struct mfcc_plan {
     int n_cu = 0;
     bool fast2048 = false;
     int variant = 0;
+    // the streamlined kernel of front_2048_fast.h is usable for this plan
+    int fast_mode = 0;
+    size_t fast_lds_bytes = 0;
     size_t front_lds_bytes = 0;
     mfcc_host::SparseMel sm;       // generic kernel: lane = filter
     mfcc_host::MelJobs mj;         // 2048-point kernel: balanced jobs
@@ -438,7 +442,9 @@ struct mfcc_plan {
     float ref_db = 0.0f;
     // device tables
     float* d_window = nullptr;
+    float4* d_window_t = nullptr;
     float2* d_tw1 = nullptr;
+    float4* d_tw1_t = nullptr;
     float2* d_w64 = nullptr;
     float2* d_tw128 = nullptr;
     float4* d_melw = nullptr;
@@ -495,6 +501,9 @@ const FrontVariant kFrontVariants[] = {
     FRONT_VARIANT(12, IN_REGS, IN_LDS, true, true, 0, 0),   // 9: both
     FRONT_VARIANT16(16, IN_LDS, IN_LDS, false, true, 0),    // 10: 16 wavefronts, any hop
     FRONT_VARIANT16(16, IN_LDS, IN_LDS, false, false, 0),   // 11: same, mel weights streamed
+    FRONT_VARIANT16(16, IN_GLOBAL, IN_LDS, false, true, 0),   // 12: window from global memory
+    FRONT_VARIANT16(16, IN_LDS, IN_GLOBAL, false, true, 0),   // 13: step-1 twiddles from global memory
+    FRONT_VARIANT16(16, IN_GLOBAL, IN_GLOBAL, false, true, 0),   // 14: both
 };
 // power != 2: same structure as variants 0 (mel weights streamed) and 1 (mel weights in LDS).
 const FrontVariant kFrontGeneralPower[] = {
@@ -502,6 +511,9 @@ const FrontVariant kFrontGeneralPower[] = {
     FRONT_VARIANT16(12, IN_LDS, IN_LDS, false, true, 1),
 };
 constexpr int kNumFrontVariants = sizeof(kFrontVariants) / sizeof(kFrontVariants[0]);
+
+typedef void (*FrontFn)(const FrontArgs);
+FrontFn fast_kernel(bool pcm16) { return pcm16 ? k_melspec_2048_fast<16, true> : k_melspec_2048_fast<16, false>; }
 
 int select_variant(mfcc_plan* p) {
     const int melw_floats = (int)p->mj.w.size() + 2 * 64 * p->mj.n_jobs;   // weights + job table
@@ -526,6 +538,25 @@ int select_variant(mfcc_plan* p) {
     p->front = kFrontVariants[v];
     if (p->r.c.power != 2.0f) p->front = kFrontGeneralPower[p->front.melw_lds ? 1 : 0];
     p->variant = v;
+    // The reference's shape takes the streamlined kernel (MFCC_HIP_FAST = 0 keeps the general one, as
+    // does MFCC_HIP_VARIANT, which asks for one of its variants).
+    p->fast_mode = 0;
+    p->fast_lds_bytes = k2048::fast_lds_bytes(16, k2048::MEL_REG_JOBS);
+    const bool shape_ok = p->r.c.power == 2.0f && p->mj.n_jobs == k2048::MEL_REG_JOBS && !p->mj.shared &&
+                          p->mj.rows[0] == 1 && p->mj.rows[1] == 2 && p->mj.rows[2] == 0 && p->mj.rows[3] == 0 &&
+                          (p->mj.zero_rows & ~4u) == 0 && p->r.c.n_mels > 64 && p->r.c.n_mels <= 128 &&
+                          p->fast_lds_bytes <= (size_t)k2048::LDS_LIMIT;
+    if (shape_ok && !std::getenv("MFCC_HIP_VARIANT")) {
+        p->fast_mode = 1;
+        if (const char* e = std::getenv("MFCC_HIP_FAST")) p->fast_mode = std::atoi(e) != 0;
+    }
+    if (p->fast_mode) {
+        for (bool pcm16 : {false, true}) {
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(fast_kernel(pcm16)),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->fast_lds_bytes);
+            if (e2 != hipSuccess) return fail(MFCC_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e2));
+        }
+    }
     p->front_lds_bytes = k2048::lds_bytes(p->front.waves, p->front.win, p->front.tw1, p->front.w64_regs,
                                          p->front.melw_lds ? melw_floats : 0);
     for (auto fn : {p->front.fn, p->front.fn16}) {
@@ -898,6 +929,20 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
     int rc = MFCC_OK;
     if (rc == MFCC_OK) rc = upload(winf, &p->d_window);
     if (rc == MFCC_OK) rc = upload(tw1, &p->d_tw1);
+    if (rc == MFCC_OK && p->fast2048) {
+        // lane-major copies for the kernel variants that read these tables from global memory
+        std::vector<float4> wt(64 * 8), tt(64 * 8);
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                wt[l * 8 + j] = make_float4(winf[l + 64 * (4 * j)], winf[l + 64 * (4 * j + 1)], winf[l + 64 * (4 * j + 2)],
+                                            winf[l + 64 * (4 * j + 3)]);
+                const float2 a = tw1[(2 * j) * 64 + l];                                  // k2 = 2 j + 1
+                const float2 b = j < 7 ? tw1[(2 * j + 1) * 64 + l] : make_float2(0.0f, 0.0f);   // k2 = 2 j + 2
+                tt[l * 8 + j] = make_float4(a.x, a.y, b.x, b.y);
+            }
+        rc = upload(wt, &p->d_window_t);
+        if (rc == MFCC_OK) rc = upload(tt, &p->d_tw1_t);
+    }
     if (rc == MFCC_OK) rc = upload(w64, &p->d_w64);
     if (rc == MFCC_OK) rc = upload(tw128, &p->d_tw128);
     if (rc == MFCC_OK) {
@@ -931,6 +976,7 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
 void mfcc_plan_destroy(mfcc_plan* p) {
     if (!p) return;
     (void)hipFree(p->d_window); (void)hipFree(p->d_tw1); (void)hipFree(p->d_w64);
+    (void)hipFree(p->d_window_t); (void)hipFree(p->d_tw1_t);
     (void)hipFree(p->d_tw128); (void)hipFree(p->d_melw); (void)hipFree(p->d_mel_start);
     (void)hipFree(p->d_mel_filt); (void)hipFree(p->d_mel_pass); (void)hipFree(p->d_mel_jobs);
     (void)hipFree(p->d_dct_frag);
@@ -1016,6 +1062,7 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     FrontArgs fa;
     fa.pcm = d_pcm; fa.pcm16 = pcm16 ? 1 : 0; fa.tiles = tiles; fa.hdr = hdr;
     fa.window = plan->d_window; fa.tw1 = plan->d_tw1; fa.w64 = plan->d_w64; fa.tw128 = plan->d_tw128;
+    fa.window_t = plan->d_window_t; fa.tw1_t = plan->d_tw1_t;
     fa.melw = plan->d_melw; fa.mel_jobs = plan->d_mel_jobs;
     fa.mel_out = mel_out; fa.spec_out = spec_out; fa.gmax = gmax;
     fa.n_jobs = plan->mj.n_jobs; fa.n_mels = plan->r.c.n_mels;
@@ -1040,6 +1087,13 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     const int64_t wg_needed = (L.ub_tiles * TILE_FRAMES + fv.waves - 1) / fv.waves;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(wg_needed, plan->n_cu));
     if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
+    if (plan->fast_mode && mel_out && !spec_out) {
+        FrontFn fn = fast_kernel(pcm16);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(16 * 64), plan->fast_lds_bytes, st, fa);
+        if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[1], st));
+        HIP_TRY(hipGetLastError());
+        return MFCC_OK;
+    }
     hipLaunchKernelGGL(pcm16 ? fv.fn16 : fv.fn, dim3(grid), dim3(fv.waves * 64), plan->front_lds_bytes, st, fa);
     if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[1], st));
     (void)total_frames;

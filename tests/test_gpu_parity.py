@@ -408,12 +408,13 @@ def test_small_db_dct_kernel_matches_general_kernel(S, kw):
 def test_config5_long_utterances(S):
     """BASELINE config 5: utterances of 30-60 s (938-1876 frames each, many tiles per utterance,
     one top_db maximum across all of them), n_fft 2048, hop 512, 128 mels, top_db 80 -- plus one
-    45 s utterance that is noise at the 1e-5 level with a single full-scale click, so that
-    almost every band of it sits on the top_db floor set by one frame."""
+    45 s utterance that is noise at the 2e-6 level (about -99 dB per mel band) with a single
+    full-scale click (-11.5 dB), so that almost every band of it sits on the top_db floor set by
+    one frame."""
     rng = np.random.default_rng(5)
     lens = (rng.uniform(30.0, 60.0, size=6) * SR).astype(np.int64)
     ys = [speech_like(int(n), seed=500 + i) * np.float32(10.0 ** (-i / 3.0)) for i, n in enumerate(lens)]
-    click = (1e-5 * rng.standard_normal(45 * SR)).astype(np.float32)
+    click = (2e-6 * rng.standard_normal(45 * SR)).astype(np.float32)
     click[17 * SR + 123] = 0.999
     ys.insert(3, click)
     feats = S.mfcc_batch(ys, n_fft=2048, hop_length=512, n_mfcc=13)

@@ -3,7 +3,9 @@
 events) of each library for one configuration, every library in a fresh child process, the whole
 list repeated so that drift between runs shows.
 
-    python tools/lib_ab.py <ref|asr512|asr400|fft1024> <hours> lib1.so [lib2.so ...]"""
+    python tools/lib_ab.py <ref|asr512|asr400|fft1024> <hours> lib1.so[:VAR=VALUE[:VAR=VALUE...]] [lib2.so ...]
+
+A library may be followed by environment settings for its run (e.g. build/ab/x.so:MFCC_HIP_FAST=1)."""
 
 import os
 import subprocess
@@ -34,11 +36,13 @@ print(json.dumps({'front_ms': round(r['front_kernel_ms'], 4), 'db_dct_ms': round
 def main():
     which, hours, libs = sys.argv[1], float(sys.argv[2]), sys.argv[3:]
     for rep in range(2):
-        for lib in libs:
+        for spec in libs:
+            lib, *sets = spec.split(":")
             env = dict(os.environ, MFCC_HIP_LIBRARY=str(Path(lib).resolve()))
+            env.update(dict(kv.split("=", 1) for kv in sets))
             r = subprocess.run([sys.executable, "-c", CHILD % (str(ROOT), which, hours)], env=env,
                                capture_output=True, text=True, timeout=300)
-            print(rep, Path(lib).name, r.stdout.strip().splitlines()[-1] if r.returncode == 0 else r.stderr[-600:],
+            print(rep, spec, r.stdout.strip().splitlines()[-1] if r.returncode == 0 else r.stderr[-600:],
                   flush=True)
 
 
