@@ -146,6 +146,21 @@ int mfcc_execute_pcm16(const mfcc_plan* plan, const int16_t* d_pcm16, const int6
                        int64_t total_frames, float* d_out, float* d_melspec_out, void* d_workspace,
                        size_t workspace_bytes, void* stream);
 
+/* mfcc_execute for callers that cannot allocate device memory or hand over a workspace (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same inputs, outputs and results as mfcc_execute(..., d_melspec_out = NULL, ...); the
+ * workspace (tile table, per-utterance maxima, mel power) lives in a static device array of
+ * MFCC_NOALLOC_SCRATCH_BYTES inside the library, one copy per GPU, held until the process ends.
+ * The call allocates and frees nothing.  A batch whose mfcc_workspace_bytes() exceeds that size is
+ * refused with MFCC_E_WORKSPACE (at the reference's settings about 130 000 frames, 1.1 hours of
+ * 16 kHz audio).  The plan's device must be current.  All calls on one GPU share that GPU's array:
+ * calls that overlap in time on one GPU (different streams or threads) race; calls on one stream,
+ * or otherwise ordered, are safe -- every call initialises what it reads. */
+#define MFCC_NOALLOC_SCRATCH_BYTES (64u * 1024u * 1024u)
+int mfcc_execute_noalloc(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sample_offsets,
+                         const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
+                         int64_t total_frames, float* d_out, void* stream);
+
 /* Waits for `stream` and reports what the kernels of the last mfcc_execute* on this workspace
  * found wrong with their device-side inputs: MFCC_E_INVALID if a d_group value lay outside
  * [0, n_utts) (the kernels give such an utterance a maximum of its own instead of indexing out of

@@ -18,6 +18,8 @@ MFCC_E_HIP = -3
 MFCC_E_WORKSPACE = -4
 MFCC_E_NOMEM = -5
 
+NOALLOC_SCRATCH_BYTES = 64 * 1024 * 1024   # MFCC_NOALLOC_SCRATCH_BYTES
+
 PAD_CONSTANT = 0
 PAD_REFLECT = 1
 
@@ -87,6 +89,8 @@ SYMBOLS = {
     "mfcc_execute_pcm16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
+    "mfcc_execute_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "mfcc_workspace_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mfcc_execute_spectrogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,

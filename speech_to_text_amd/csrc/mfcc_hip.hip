@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,11 @@
 #include "front_pow2.h"
 #include "front_400.h"
 #include "host_tables.h"
+
+// Workspace of mfcc_execute_noalloc: one copy per GPU, resident from library load until the process
+// ends.  Host code never uses this name as an address: mfcc_plan_create asks the runtime for the
+// current device's copy (hipGetSymbolAddress) and keeps that pointer in the plan.
+static __device__ __align__(256) unsigned char scratch[MFCC_NOALLOC_SCRATCH_BYTES];
 
 namespace {
 
@@ -381,6 +387,26 @@ __global__ __launch_bounds__(256) void k_delta(const DeltaArgs a) {
     }
 }
 
+// Device address of `scratch` on each GPU this process has made a plan on.
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[MAX_DEVICES] = {};
+
+// The current device's copy of the static scratch array; `device` must be the current device.
+int static_scratch_of(int device, void** out) {
+    if (device < 0 || device >= MAX_DEVICES) return fail(MFCC_E_UNSUPPORTED, "device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr || reinterpret_cast<uintptr_t>(ptr) % 256)
+            return fail(MFCC_E_HIP, "hipGetSymbolAddress returned an unusable address for the static scratch");
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return MFCC_OK;
+}
+
 template <typename T>
 int upload(const std::vector<T>& h, T** d) {
     *d = nullptr;
@@ -473,6 +499,8 @@ struct mfcc_plan {
     hipEvent_t (*ev_ring)[3] = nullptr;
     mutable int64_t ev_count = 0;                    // executes recorded since profiling was (re)enabled
     mutable hipEvent_t* ev = nullptr;                // the triple of the execute being recorded
+    // the no-allocation entry point's workspace: this device's copy of the static scratch array
+    void* static_scratch = nullptr;
 };
 
 namespace {
@@ -926,7 +954,7 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
             }
     p->ref_db = (float)(10.0 * std::log10(std::max((double)r.c.amin, std::fabs((double)r.c.ref))));
 
-    int rc = MFCC_OK;
+    int rc = static_scratch_of(p->device, &p->static_scratch);
     if (rc == MFCC_OK) rc = upload(winf, &p->d_window);
     if (rc == MFCC_OK) rc = upload(tw1, &p->d_tw1);
     if (rc == MFCC_OK && p->fast2048) {
@@ -1182,6 +1210,25 @@ int mfcc_execute_pcm16(const mfcc_plan* plan, const int16_t* d_pcm16, const int6
                        size_t workspace_bytes, void* stream) {
     return execute_impl(plan, d_pcm16, true, d_sample_offsets, d_frame_offsets, d_group, n_utts, total_frames,
                         d_out, d_melspec_out, d_workspace, workspace_bytes, stream);
+}
+
+int mfcc_execute_noalloc(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sample_offsets,
+                         const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
+                         int64_t total_frames, float* d_out, void* stream) {
+    if (!plan) return fail(MFCC_E_INVALID, "plan is NULL");
+    if (n_utts < 0 || total_frames < 0) return fail(MFCC_E_INVALID, "negative batch size");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != plan->device)
+        return fail(MFCC_E_INVALID, "the plan was made on device " + std::to_string(plan->device) +
+                                        " but the current device is " + std::to_string(dev));
+    const size_t need = ws_layout(total_frames, n_utts, plan->r.c.n_mels, true).total;
+    if (need > (size_t)MFCC_NOALLOC_SCRATCH_BYTES)
+        return fail(MFCC_E_WORKSPACE, "batch needs " + std::to_string(need) + " bytes of workspace, the static scratch of "
+                                      "mfcc_execute_noalloc holds " + std::to_string((size_t)MFCC_NOALLOC_SCRATCH_BYTES) +
+                                      ": split the batch or call mfcc_execute with a workspace of your own");
+    return execute_impl(plan, d_pcm, false, d_sample_offsets, d_frame_offsets, d_group, n_utts, total_frames, d_out,
+                        nullptr, plan->static_scratch, (size_t)MFCC_NOALLOC_SCRATCH_BYTES, stream);
 }
 
 int mfcc_plan_set_profiling(mfcc_plan* plan, int enable) {
