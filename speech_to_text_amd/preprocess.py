@@ -8,9 +8,12 @@
     read_preprocessed_data()      :169-176   walk mfcc/ and print datasets + attrs
 
 The arithmetic runs on the GPU in ragged batches; audio decode and resampling stay on the host
-(the dataset is any iterable of LibriSpeech-style items, e.g. torchaudio.datasets.LIBRISPEECH as
-the reference builds it at :75).  Where the reference parallelises over worker processes
-(``multiprocess=True``), this driver parallelises the file writing over threads instead.
+(the dataset is any sequence or iterable of LibriSpeech-style items, e.g.
+torchaudio.datasets.LIBRISPEECH as the reference builds it at :75).  The dataset is walked lazily,
+as the reference walks it: a rank decodes only its own utterances (``data[i]`` in a few threads, a
+bounded number of samples ahead of the GPU, results taken in completion order like
+``imap_unordered`` at :160), cuts them into batches, and while the GPU works on one batch the next
+is being decoded and the previous one's files are being written.
 """
 from __future__ import annotations
 
@@ -22,7 +25,7 @@ from typing import Iterable, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import hdf5_min
-from .shard import lpt_shards, pack_batches
+from .ingest import DecodeAhead, iter_batches, shard_indices
 
 Item = Tuple  # (waveform (1, T) float32 tensor-or-ndarray, sample_rate, transcript, speaker, chapter, utterance)
 
@@ -105,11 +108,20 @@ class Preprocessor:
     - rank / world_size: this process's shard of the utterances (one process per GPU)
     - ingest: 'float32' uploads the waveforms as they are; 'int16' uploads 16-bit PCM whenever
       every waveform of a batch lies on the int16 grid (bit-identical features, half the upload)
+    - lengths: optional manifest, samples per item (from file sizes or a metadata table): the
+      ranks' shards are then balanced by frame count; without it items are dealt round-robin.
+      Either way no audio is decoded to decide who takes what.
+    - decode_workers: threads that run ``data[i]`` ahead of the GPU (default: up to 8)
+    - max_batch_seconds: audio per GPU batch, counted at 16 kHz; at most about two batches of
+      waveforms are alive at any time (the one on the GPU and the one being decoded)
     """
+
+    NOMINAL_SR = 16000
 
     def __init__(self, data: Optional[Iterable[Item]] = None, out_dir: str = "mfcc", *, device=None,
                  rank: int = 0, world_size: int = 1, max_batch_seconds: float = 1800.0,
-                 hdf5_backend: Optional[str] = None, extractor=None, ingest: str = "float32"):
+                 hdf5_backend: Optional[str] = None, extractor=None, ingest: str = "float32",
+                 lengths: Optional[Sequence[int]] = None, decode_workers: Optional[int] = None):
         # MFCC meta parameters, as /root/reference/src/preprocess.py:60-62
         self.hop_length = 512
         self.n_fft = 2048
@@ -124,6 +136,9 @@ class Preprocessor:
         if ingest not in ("float32", "int16"):
             raise ValueError("ingest must be 'float32' or 'int16'")
         self.ingest = ingest
+        self.lengths = lengths
+        self.decode_workers = decode_workers
+        self.stats: dict = {}
 
     # ------------------------------------------------------------------------------------
     def _features(self, waveforms: Sequence[np.ndarray]) -> List[np.ndarray]:
@@ -170,58 +185,77 @@ class Preprocessor:
         frames = self._features([samples])[0]          # == librosa.feature.mfcc(y=samples)[0].T
         self._write(item, frames)
 
+    def _decoded_stream(self, multiprocess: bool):
+        """(index, item) pairs of this rank's utterances, plus the number it will yield (None if
+        unknown) and the DecodeAhead behind it (None for a plain iterable)."""
+        data = self.data
+        budget = int(self.max_batch_seconds * self.NOMINAL_SR)
+        if hasattr(data, "__len__") and hasattr(data, "__getitem__"):
+            mine = shard_indices(len(data), self.rank, self.world_size, self.lengths, self.hop_length)
+            workers = self.decode_workers or max(1, min(8, (os.cpu_count() or 2) - 1))
+            if multiprocess:                       # the reference's pool size, /root/reference/src/preprocess.py:156
+                workers = max(workers, min(32, (os.cpu_count() or 2) - 1 or 1))
+            ahead = DecodeAhead(data.__getitem__, mine, lambda it: it[0].shape[-1], workers=workers,
+                                budget_samples=budget)
+            return ahead, len(mine), ahead
+        # a plain iterable can only be walked in order: every rank walks it and keeps its share
+        return ((i, it) for i, it in enumerate(data) if i % self.world_size == self.rank), None, None
+
     def preprocess(self, multiprocess: bool = False, verbose: bool = True, packed: bool = False) -> int:
         """/root/reference/src/preprocess.py:146-167: every item of ``self.data`` -> one file.
-        Returns the number of utterances this rank wrote.  While the writer threads store batch
-        k the GPU already works on batch k + 1.  ``packed=True`` writes this rank's utterances to
-        one file ``out_dir/packed_{rank:05d}.hdf5`` instead (sink.write_packed)."""
+        Returns the number of utterances this rank wrote.  The dataset is never materialised:
+        decode threads run ahead of the GPU by at most one batch of samples, the GPU takes one
+        batch at a time, and a writer thread stores batch k while batch k + 1 is on the GPU.
+        ``multiprocess=True`` raises the decode threads to the reference's pool size.
+        ``packed=True`` writes this rank's utterances to one file
+        ``out_dir/packed_{rank:05d}.hdf5`` instead (sink.write_packed)."""
         if self.data is None:
             print("Data is empty. Aborted.")
             return 0
         self.out_dir.mkdir(parents=True, exist_ok=True)
-        items = list(self.data)
-        lengths = np.asarray([_waveform_to_numpy(it[0]).shape[-1] for it in items], dtype=np.int64)
-        costs = 1 + lengths // self.hop_length
-        mine = lpt_shards(costs, self.world_size)[self.rank] if self.world_size > 1 else np.arange(len(items))
-        sr = int(items[0][1]) if items else 16000
-        batches = pack_batches(lengths[mine], int(self.max_batch_seconds * sr))
+        stream, n_mine, ahead = self._decoded_stream(multiprocess)
+        budget = int(self.max_batch_seconds * self.NOMINAL_SR)
         # One writer thread: per file the writers spend more time in the interpreter (arguments,
         # byte strings) than in I/O, so more threads only add hand-overs of its lock -- measured
         # slower with 4 threads than with 1 for all three backends.
-        n_threads = 1
         if verbose:
-            print(f"Processing audio data... rank {self.rank}/{self.world_size}: {len(mine)} of {len(items)} "
-                  f"utterances in {len(batches)} GPU batch(es), {n_threads} writer thread(s)")
-        done = 0
-        kept, kept_idx = [], []
-        with ThreadPoolExecutor(max_workers=n_threads) as pool:
-            pending = []
-            for b in batches:
-                idx = mine[b]
-                feats = self._features([_waveform_to_numpy(items[i][0]) for i in idx])
-                for f in pending:
-                    f.result()
+            print(f"Processing audio data... rank {self.rank}/{self.world_size}: "
+                  f"{n_mine if n_mine is not None else '?'} utterances, GPU batches of up to "
+                  f"{self.max_batch_seconds:g} s of audio, 1 writer thread")
+        done = n_batches = peak_batch = 0
+        kept, kept_meta = [], []
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pending = None
+            for _idx, items in iter_batches(stream, lambda it: it[0].shape[-1], budget):
+                waves = [_waveform_to_numpy(it[0]) for it in items]
+                peak_batch = max(peak_batch, sum(int(w.shape[-1]) for w in waves))
+                feats = self._features(waves)
+                metas = [it[1:] for it in items]                 # the waveforms can go now
+                del waves, items
+                if pending is not None:
+                    pending.result()
                 if packed:
                     kept.extend(feats)
-                    kept_idx.extend(int(i) for i in idx)
-                    pending = []
+                    kept_meta.extend(metas)
                 else:
-                    # one task per writer thread: the writers are Python code, so a task per file
-                    # costs more in hand-over than the file itself
-                    pairs = [(items[i], fr) for i, fr in zip(idx, feats)]
-                    step = -(-len(pairs) // n_threads)
-                    pending = [pool.submit(self._write_many, pairs[k:k + step]) for k in range(0, len(pairs), step)]
-                done += len(idx)
+                    pairs = [((None,) + tuple(m), fr) for m, fr in zip(metas, feats)]
+                    pending = pool.submit(self._write_many, pairs)
+                done += len(feats)
+                n_batches += 1
                 if verbose:
-                    print(f"Progress: {done}/{len(mine)}", end="\r")
-            for f in pending:
-                f.result()
+                    print(f"Progress: {done}/{n_mine if n_mine is not None else '?'}", end="\r")
+            if pending is not None:
+                pending.result()
         if packed:
             from .sink import write_packed
 
-            metas = [dict(sample_rate=items[i][1], transcript=items[i][2], speaker_id=items[i][3],
-                          chapter_id=items[i][4], utterance_id=items[i][5]) for i in kept_idx]
+            metas = [dict(sample_rate=m[0], transcript=m[1], speaker_id=m[2], chapter_id=m[3], utterance_id=m[4])
+                     for m in kept_meta]
             write_packed(self.out_dir / f"packed_{self.rank:05d}.hdf5", kept, metas, backend=self.hdf5_backend)
+        self.stats = {"utterances": done, "batches": n_batches, "peak_batch_samples": peak_batch,
+                      "batch_budget_samples": budget,
+                      "decode_calls": ahead.n_fetched if ahead is not None else None,
+                      "peak_decoded_ahead_samples": ahead.peak_ahead if ahead is not None else None}
         if verbose:
             print()
         return done

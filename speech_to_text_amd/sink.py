@@ -123,18 +123,22 @@ class FeatureDataset:
     ``(F, n_mfcc)`` device tensor.  ``extractor`` is injectable for host-only tests."""
 
     def __init__(self, data, *, device=None, n_fft=2048, hop_length=512, n_mfcc=13, max_batch_seconds=1800.0,
-                 ingest="float32", extractor=None):
-        from .preprocess import _waveform_to_numpy
-        from .shard import pack_batches
+                 ingest="float32", extractor=None, decode_workers=None):
+        from .ingest import DecodeAhead, iter_batches
+        from .preprocess import Preprocessor, _waveform_to_numpy
 
-        items = list(data)
-        waves = [_waveform_to_numpy(it[0]).reshape(-1) for it in items]
-        self._meta = [[int(it[1]), str(it[2]), int(it[3])] for it in items]
-        lengths = np.asarray([w.shape[-1] for w in waves], dtype=np.int64)
-        sr = int(items[0][1]) if items else 16000
-        self._feats = [None] * len(items)
-        for b in pack_batches(lengths, int(max_batch_seconds * sr)):
-            chunk = [waves[i] for i in b]
+        # the dataset is walked lazily, a batch of waveforms at a time (the features are 40 times
+        # smaller than the audio and stay)
+        budget = int(max_batch_seconds * Preprocessor.NOMINAL_SR)
+        if hasattr(data, "__len__") and hasattr(data, "__getitem__"):
+            workers = decode_workers or max(1, min(8, (os.cpu_count() or 2) - 1))
+            stream = DecodeAhead(data.__getitem__, range(len(data)), lambda it: it[0].shape[-1], workers=workers,
+                                 budget_samples=budget)
+        else:
+            stream = enumerate(data)
+        feats, meta = {}, {}
+        for idx, items in iter_batches(stream, lambda it: it[0].shape[-1], budget):
+            chunk = [_waveform_to_numpy(it[0]).reshape(-1) for it in items]
             if extractor is not None:
                 outs = extractor(chunk, n_fft=n_fft, hop_length=hop_length, n_mfcc=n_mfcc)
             else:
@@ -142,8 +146,12 @@ class FeatureDataset:
 
                 outs = mfcc_batch(chunk, n_fft=n_fft, hop_length=hop_length, n_mfcc=n_mfcc, device=device,
                                   return_tensor=True, int16_if_exact=ingest == "int16")
-            for i, o in zip(b, outs):
-                self._feats[int(i)] = o
+            for i, it, o in zip(idx, items, outs):
+                feats[int(i)] = o
+                meta[int(i)] = [int(it[1]), str(it[2]), int(it[3])]
+        order = sorted(feats)
+        self._feats = [feats[i] for i in order]
+        self._meta = [meta[i] for i in order]
 
     def __len__(self) -> int:
         return len(self._feats)

@@ -1,5 +1,6 @@
 """Host-side logic without a GPU: sharding, HDF5 schema round trips, the preprocessing driver
 (with the oracle injected as the feature extractor)."""
+import os
 import shutil
 import subprocess
 from pathlib import Path
@@ -252,3 +253,97 @@ def test_native_feature_file_writer_matches_python_writer(tmp_path):
     with pytest.raises(TypeError):
         hdf5_min.write_many_features_native([tmp_path / "a.hdf5", tmp_path / "b.hdf5"], arrays[:2],
                                             [dict(x=1), dict(x="s")])
+
+
+class _SlowDataset:
+    """Sequence whose __getitem__ stands in for a FLAC decode: it sleeps, counts its calls and
+    hands out a fresh waveform every time (so nothing can be shared between calls)."""
+
+    def __init__(self, n, seed=0, delay=0.002):
+        import threading
+
+        self.lens = ragged_lengths(n, 0.2, 1.5, seed=seed)
+        self.calls = np.zeros(n, dtype=np.int64)
+        self.delay = delay
+        self._lock = threading.Lock()
+
+    def __len__(self):
+        return len(self.lens)
+
+    def __getitem__(self, i):
+        import time
+
+        time.sleep(self.delay)
+        with self._lock:
+            self.calls[i] += 1
+        return (speech_like(int(self.lens[i]), seed=1000 + i)[None, :], 16000, f"TEXT {i}", 3 + i, 7 + i, i)
+
+
+def _oracle_extract(waveforms, *, n_fft, hop_length, n_mfcc):
+    return [R.process_audio_features(np.asarray(w).reshape(-1), n_fft=n_fft, hop_length=hop_length, n_mfcc=n_mfcc)
+            for w in waveforms]
+
+
+@pytest.mark.parametrize("manifest", [False, True])
+def test_streaming_preprocess_fetches_each_item_once_with_bounded_memory(tmp_path, manifest):
+    """The driver walks its dataset lazily (as /root/reference/src/preprocess.py:155-167 does): over
+    a whole world every item is decoded exactly once, a rank never holds more than about two
+    batches of waveforms, and the files equal those of the one-item-at-a-time path."""
+    n, world = 40, 2
+    ds = _SlowDataset(n)
+    budget_s = 4.0
+    written = 0
+    for rank in range(world):
+        pre = Preprocessor(ds, out_dir=tmp_path / "mfcc", rank=rank, world_size=world, extractor=_oracle_extract,
+                           hdf5_backend="min", max_batch_seconds=budget_s, decode_workers=3,
+                           lengths=ds.lens if manifest else None)
+        written += pre.preprocess(verbose=False)
+        st = pre.stats
+        assert st["batches"] >= 3                                    # really streamed in pieces
+        assert st["peak_batch_samples"] <= st["batch_budget_samples"]
+        # decoded ahead of the GPU: at most one batch, plus one utterance per decode thread
+        assert st["peak_decoded_ahead_samples"] <= st["batch_budget_samples"] + 3 * int(ds.lens.max())
+        assert st["decode_calls"] == st["utterances"]
+    assert written == n and (ds.calls == 1).all()
+    files = sorted(os.listdir(tmp_path / "mfcc"))
+    assert len(files) == n and not any(f.endswith(".tmp") for f in files)
+    one = Preprocessor(None, out_dir=tmp_path / "single", extractor=_oracle_extract, hdf5_backend="min")
+    for i in (0, 17, n - 1):
+        item = _SlowDataset(n)[i]
+        one.process_audio(item)
+        name = feature_file_name(item[3], item[4], item[5])
+        assert (tmp_path / "mfcc" / name).read_bytes() == (tmp_path / "single" / name).read_bytes()
+
+
+def test_streaming_preprocess_plain_iterable_and_worker_error(tmp_path):
+    """A generator (no len, no indexing) is walked in order by every rank, each keeping its share;
+    an exception in a decode thread reaches the caller, as it does from imap_unordered."""
+    ds = _SlowDataset(9, delay=0.0)
+    total = 0
+    for rank in range(2):
+        pre = Preprocessor((ds[i] for i in range(len(ds))), out_dir=tmp_path / "gen", rank=rank, world_size=2,
+                           extractor=_oracle_extract, hdf5_backend="min", max_batch_seconds=2.0)
+        total += pre.preprocess(verbose=False)
+    assert total == 9 and len(os.listdir(tmp_path / "gen")) == 9
+
+    class Broken(_SlowDataset):
+        def __getitem__(self, i):
+            if i == 5:
+                raise OSError("corrupt file")
+            return super().__getitem__(i)
+
+    pre = Preprocessor(Broken(9, delay=0.0), out_dir=tmp_path / "bad", extractor=_oracle_extract, hdf5_backend="min",
+                       max_batch_seconds=2.0)
+    with pytest.raises(OSError, match="corrupt file"):
+        pre.preprocess(verbose=False)
+
+
+def test_feature_dataset_streams_its_source():
+    from speech_to_text_amd.sink import FeatureDataset
+
+    ds = _SlowDataset(12, delay=0.0)
+    fd = FeatureDataset(ds, extractor=_oracle_extract, max_batch_seconds=3.0, decode_workers=2)
+    assert len(fd) == 12 and (ds.calls == 1).all()
+    for i in (0, 5, 11):
+        want = R.process_audio_features(speech_like(int(ds.lens[i]), seed=1000 + i))
+        assert np.array_equal(fd[i][0], want) and fd[i][1:] == [16000, f"TEXT {i}", 3 + i]

@@ -4,10 +4,12 @@ Preprocessor.preprocess (the reference's `--preprocess`, /root/reference/src/pre
 
     python tools/bench_preprocess.py [--hours H] [--out file.json]
 
-Variants: one HDF5 file per utterance as the reference writes them (writer threads), one packed
-file per rank, and the packed file with 16-bit PCM ingest.  The waveforms are synthetic
-(LibriSpeech-like lengths, values on the int16 grid) and already decoded in host memory: FLAC
-decode is outside this path."""
+Variants: one HDF5 file per utterance as the reference writes them, one packed file per rank, the
+packed file with 16-bit PCM ingest, and the per-utterance files from a LAZY dataset whose
+``__getitem__`` produces the float32 waveform on demand (int16 -> float32, the last step of a
+decode), in batches of 30 minutes of audio, which is how a corpus larger than host memory runs.
+The waveforms are synthetic (LibriSpeech-like lengths, values on the int16 grid); FLAC decode
+itself is outside this path."""
 from __future__ import annotations
 
 import argparse
@@ -40,6 +42,20 @@ def make_items(hours: float, seed: int = 3):
         total += n
         u += 1
     return items, total / SR / 3600.0
+
+
+class LazyDataset:
+    """Holds 16-bit PCM; an item's float32 waveform exists only between __getitem__ and the GPU batch."""
+
+    def __init__(self, items):
+        self.pcm = [np.rint(it[0][0] * 32768.0).astype(np.int16) for it in items]
+        self.meta = [it[1:] for it in items]
+
+    def __len__(self):
+        return len(self.pcm)
+
+    def __getitem__(self, i):
+        return ((self.pcm[i].astype(np.float32) / np.float32(32768.0))[None, :],) + tuple(self.meta[i])
 
 
 def timed(fn):
@@ -80,7 +96,16 @@ def main():
             size = sum(f.stat().st_size for f in out.iterdir())
             res[name] = {"seconds": dt, "audio_hours_per_s": hours / dt, "utterances": int(n), "files": files,
                          "bytes_written": size}
+            res[name]["stats"] = pre.stats
             shutil.rmtree(out)
+        lazy = LazyDataset(items)
+        out = base / "lazy"
+        pre = S.Preprocessor(lazy, str(out), max_batch_seconds=1800.0, lengths=[len(x) for x in lazy.pcm])
+        dt, n = timed(lambda: pre.preprocess(verbose=False, multiprocess=True))
+        res["lazy_dataset_files_per_utterance"] = {
+            "seconds": dt, "audio_hours_per_s": hours / dt, "utterances": int(n), "stats": pre.stats,
+            "note": "waveforms produced on demand by decode threads, 30-minute GPU batches, length manifest"}
+        shutil.rmtree(out)
     finally:
         shutil.rmtree(base, ignore_errors=True)
     text = json.dumps(res, indent=1)
