@@ -43,18 +43,22 @@ class DecodeAhead:
     """Iterates ``(index, fetch(index))`` over ``indices`` in completion order.  ``fetch`` runs in
     ``workers`` threads; a new fetch starts only while the samples of the results that have been
     fetched but not yet taken stay below ``budget_samples`` (so at most that many samples, plus
-    one utterance per worker, wait in host memory).  ``size_of(result)`` gives a result's samples.
+    one chunk of utterances per worker, wait in host memory).  ``size_of(result)`` gives a result's samples.
+
+    Indices are handed to the workers ``chunk`` at a time (one task, one hand-over per chunk: for
+    cheap fetches the hand-over, not the fetch, is the cost).
 
     ``peak_ahead`` records the most samples that ever waited; ``n_fetched`` the number of fetches."""
 
     _END = object()
 
     def __init__(self, fetch: Callable[[int], object], indices: Iterable[int], size_of: Callable[[object], int],
-                 workers: int = 4, budget_samples: int = 1 << 26):
+                 workers: int = 4, budget_samples: int = 1 << 26, chunk: int = 8):
         self._fetch, self._size_of = fetch, size_of
         self._indices = iter(indices)
         self._workers = max(1, int(workers))
         self._budget = max(1, int(budget_samples))
+        self._chunk = max(1, int(chunk))
         self._out: "queue.Queue" = queue.Queue()
         self._cv = threading.Condition()
         self._ahead = 0            # samples fetched and not yet taken
@@ -69,14 +73,17 @@ class DecodeAhead:
 
     def _feed(self) -> None:
         try:
+            todo = []
             for i in self._indices:
-                with self._cv:
-                    while not self._stop and (self._inflight >= self._workers or self._ahead >= self._budget):
-                        self._cv.wait()
-                    if self._stop:
-                        break
-                    self._inflight += 1
-                self._pool.submit(self._run, int(i))
+                todo.append(int(i))
+                if len(todo) < self._chunk:
+                    continue
+                if not self._submit(todo):
+                    todo = []
+                    break
+                todo = []
+            if todo:
+                self._submit(todo)
         except BaseException as e:                       # the index iterable itself failed
             with self._cv:
                 self._error = self._error or e
@@ -86,17 +93,27 @@ class DecodeAhead:
                     self._cv.wait()
             self._out.put(self._END)
 
-    def _run(self, i: int) -> None:
+    def _submit(self, idx) -> bool:
+        with self._cv:
+            while not self._stop and (self._inflight >= self._workers or self._ahead >= self._budget):
+                self._cv.wait()
+            if self._stop:
+                return False
+            self._inflight += 1
+        self._pool.submit(self._run, idx)
+        return True
+
+    def _run(self, idx) -> None:
         try:
-            res = self._fetch(i)
-            n = int(self._size_of(res))
+            res = [self._fetch(i) for i in idx]
+            sizes = [int(self._size_of(r)) for r in res]
             with self._cv:
                 self._inflight -= 1
-                self._ahead += n
+                self._ahead += sum(sizes)
                 self.peak_ahead = max(self.peak_ahead, self._ahead)
-                self.n_fetched += 1
+                self.n_fetched += len(idx)
                 self._cv.notify_all()
-            self._out.put((i, res, n))
+            self._out.put((idx, res, sizes))
         except BaseException as e:                       # a worker's exception reaches the consumer,
             with self._cv:                               # as it does from Pool.imap_unordered
                 self._inflight -= 1
@@ -110,11 +127,13 @@ class DecodeAhead:
                 got = self._out.get()
                 if got is self._END:
                     break
-                i, res, n = got
-                with self._cv:
-                    self._ahead -= n
-                    self._cv.notify_all()
-                yield i, res
+                idx, res, sizes = got
+                for i, r, n in zip(idx, res, sizes):
+                    with self._cv:
+                        self._ahead -= n
+                        if self._ahead < self._budget:
+                            self._cv.notify_all()
+                    yield i, r
             if self._error is not None:
                 raise self._error
         finally:

@@ -301,8 +301,8 @@ def test_streaming_preprocess_fetches_each_item_once_with_bounded_memory(tmp_pat
         st = pre.stats
         assert st["batches"] >= 3                                    # really streamed in pieces
         assert st["peak_batch_samples"] <= st["batch_budget_samples"]
-        # decoded ahead of the GPU: at most one batch, plus one utterance per decode thread
-        assert st["peak_decoded_ahead_samples"] <= st["batch_budget_samples"] + 3 * int(ds.lens.max())
+        # decoded ahead of the GPU: at most one batch, plus one chunk (8 utterances) per decode thread
+        assert st["peak_decoded_ahead_samples"] <= st["batch_budget_samples"] + 3 * 8 * int(ds.lens.max())
         assert st["decode_calls"] == st["utterances"]
     assert written == n and (ds.calls == 1).all()
     files = sorted(os.listdir(tmp_path / "mfcc"))

@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2] as written: 1000 hours of DISTINCT synthetic 16 kHz audio, ragged 2-35 s
+utterances, sharded by utterance over the ranks (LPT on frame count) and pushed through ONE plan
+and ONE workspace in resident batches of at most 8 GB of PCM, every batch generated on the device
+with a counter-based generator keyed by (seed, utterance id, sample index) and every batch with
+its own ragged layout.
+
+    python tools/bench_config3.py [--hours 1000] [--batch-gb 8] [--out file.json]
+    python -m torch.distributed.run --nproc-per-node N ... tools/bench_config3.py   (one rank per GPU)
+
+Per batch: HIP-event times of the two kernels (the library's event ring) and the wall time of the
+execute call with a synchronisation either side; generation is outside the timed region.  One
+utterance of a batch in the middle of the run is checked against the CPU oracle.  The looped
+variant (one 10 h batch, 100 passes) is tools/bench_configs.py."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import speech_to_text_amd as S  # noqa: E402
+from speech_to_text_amd.shard import lpt_shards, pack_batches  # noqa: E402
+
+SR = 16000
+SEED = 2024
+M64 = (1 << 64) - 1
+
+
+def _mix(x: torch.Tensor) -> torch.Tensor:
+    """splitmix64 finaliser on int64 tensors (wrapping arithmetic)."""
+    x = (x ^ (x >> 30).bitwise_and(0x3FFFFFFFF)) * -4658895280553007687       # 0xBF58476D1CE4E5B9
+    x = (x ^ (x >> 27).bitwise_and(0x1FFFFFFFFF)) * -7723592293110705685      # 0x94D049BB133111EB
+    return x ^ (x >> 31).bitwise_and(0x1FFFFFFFF)
+
+
+def generate_batch(utt_ids: np.ndarray, lens: np.ndarray, device) -> torch.Tensor:
+    """Speech-like audio on the int16 grid; sample s of utterance u depends on (SEED, u, s) only."""
+    so = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=so[1:])
+    total = int(so[-1])
+    d_so = torch.from_numpy(so).to(device)
+    d_id = torch.from_numpy(utt_ids.astype(np.int64)).to(device)
+    pcm = torch.empty(total, dtype=torch.float32, device=device)
+    chunk = 1 << 26
+    for a in range(0, total, chunk):
+        b = min(total, a + chunk)
+        g = torch.arange(a, b, device=device, dtype=torch.int64)
+        u = torch.bucketize(g, d_so, right=True) - 1
+        s = g - d_so[u]
+        key = _mix(_mix(d_id[u] + SEED * 1000003) + s)
+        # two 24-bit uniforms -> one Gaussian (Box-Muller)
+        u1 = ((key >> 40).bitwise_and(0xFFFFFF).to(torch.float32) + 0.5) / 16777216.0
+        u2 = ((key >> 8).bitwise_and(0xFFFFFF).to(torch.float32) + 0.5) / 16777216.0
+        noise = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(6.283185307179586 * u2)
+        t = s.to(torch.float64) / SR
+        env = torch.sin(2 * np.pi * 1.5 * t).abs().float()
+        tone = torch.sin(2 * np.pi * 220.0 * t).float()
+        y = (0.1 * noise * env + 0.3 * tone).clamp_(-0.999, 0.999)
+        pcm[a:b] = torch.round(y * 32768.0) / 32768.0
+        del g, u, s, key, u1, u2, noise, t, env, tone, y
+    return pcm, so
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hours", type=float, default=1000.0)
+    ap.add_argument("--batch-gb", type=float, default=8.0)
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # the corpus: lengths U(2, 35) s until the target is reached; the same on every rank
+    rng = np.random.default_rng(SEED)
+    target = int(args.hours * 3600 * SR)
+    n_guess = int(target / (18.5 * SR) * 1.05) + 16
+    lens = (rng.uniform(2.0, 35.0, size=n_guess) * SR).astype(np.int64)
+    n_utts = int(np.searchsorted(np.cumsum(lens), target)) + 1
+    lens = lens[:n_utts]
+    mine = lpt_shards(1 + lens // 512, world)[rank] if world > 1 else np.arange(n_utts)
+    batches = pack_batches(lens[mine], int(args.batch_gb * 1e9 / 4))
+
+    cfg = S.MfccConfig.reference_default()
+    plan = S.MfccPlan(cfg, dev)
+    plan.set_profiling(True)
+    fmax = max(int((1 + lens[mine[b]] // 512).sum()) for b in batches)
+    umax = max(len(b) for b in batches)
+    ws = plan.workspace(fmax, umax)
+    out = torch.empty((fmax, cfg.n_mfcc), dtype=torch.float32, device=dev)
+    recs, check = [], None
+    t_all = time.perf_counter()
+    for k, b in enumerate(batches):
+        ids = mine[b]
+        pcm, so = generate_batch(ids, lens[ids], dev)
+        fo = plan.frame_offsets(so)
+        d_so, d_fo = torch.from_numpy(so).to(dev), torch.from_numpy(fo).to(dev)
+        F = int(fo[-1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plan.execute(pcm, d_so, d_fo, F, out=out[:F], workspace=ws)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        front, dct = plan.last_timings()
+        hours = float(so[-1]) / SR / 3600.0
+        recs.append({"batch": k, "utterances": int(len(ids)), "audio_hours": hours, "frames": F,
+                     "pcm_GB": 4.0 * float(so[-1]) / 1e9, "front_kernel_ms": front, "db_dct_kernel_ms": dct,
+                     "execute_wall_ms": wall * 1e3, "checksum": float(out[:F].double().sum().item())})
+        if k == len(batches) // 2 and rank == 0:
+            from oracle import mfcc_ref as R
+
+            u = len(ids) // 2
+            y = pcm[int(so[u]):int(so[u + 1])].cpu().numpy()
+            got = out[int(fo[u]):int(fo[u + 1])].cpu().numpy()
+            check = {"batch": k, "utterance_id": int(ids[u]), "samples": int(len(y)),
+                     "max_abs_diff_vs_oracle_db": float(np.abs(got - R.process_audio_features(y)).max())}
+        del pcm, d_so, d_fo
+        if rank == 0:
+            print(f"batch {k + 1}/{len(batches)}: {hours:.1f} h, front {front:.3f} ms, dB+DCT {dct:.3f} ms", flush=True)
+    total_wall = time.perf_counter() - t_all
+    hours = sum(r["audio_hours"] for r in recs)
+    kern = sum(r["front_kernel_ms"] + r["db_dct_kernel_ms"] for r in recs) * 1e-3
+    exe = sum(r["execute_wall_ms"] for r in recs) * 1e-3
+    res = {"config": f"BASELINE configs[2]: {args.hours:g} h of distinct synthetic 16 kHz audio, ragged 2-35 s, "
+                     f"batches of <= {args.batch_gb:g} GB PCM generated on the device, one plan, one workspace",
+           "world_size": world, "rank": rank, "utterances_total": int(n_utts), "utterances_this_rank": int(len(mine)),
+           "audio_hours_this_rank": hours, "batches": len(recs),
+           "audio_hours_per_s_kernels": hours / kern, "audio_hours_per_s_execute_wall": hours / exe,
+           "seconds_kernels": kern, "seconds_execute_wall": exe, "seconds_total_incl_generation": total_wall,
+           "oracle_check": check, "per_batch": recs}
+    if dist is not None:
+        t = torch.tensor([exe, hours], dtype=torch.float64, device=dev)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        res["all_ranks"] = {"audio_hours": sum(float(p[1]) for p in parts), "max_seconds_execute_wall": max(float(p[0]) for p in parts)}
+        res["all_ranks"]["audio_hours_per_s"] = res["all_ranks"]["audio_hours"] / res["all_ranks"]["max_seconds_execute_wall"]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        text = json.dumps(res, indent=1)
+        print(json.dumps({k: v for k, v in res.items() if k != "per_batch"}, indent=1))
+        if args.out:
+            Path(args.out).write_text(text)
+
+
+if __name__ == "__main__":
+    main()
