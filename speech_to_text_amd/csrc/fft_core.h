@@ -6,7 +6,8 @@
 //   cfft16 : 16-point complex DFT, radix-4 x radix-4, decimation in frequency.
 //   rdft32 : 32-point DFT of a REAL sequence (bins 0..16) from one cfft16 of the packed
 //            sequence z[m] = r[2m] + i r[2m+1] plus the conjugate-symmetric split.
-//   rdft_cols<R> : the same for 2R = 4, 8, 16 points;  rdft25 : 25-point real DFT, direct.
+//   rdft_cols<R> : the same for 2R = 4, 8, 16 points;  rdft25 : 25-point real DFT (5 x 5);
+//   rdft_even<A> : 20- and 30-point real DFTs, folded direct sums.
 //
 // Forward transform convention, as numpy.fft: X[k] = sum_n x[n] exp(-2 pi i n k / N).
 #pragma once
@@ -231,6 +232,79 @@ FC_HD void rdft25(const float (&x)[25], float (&yr)[13], float (&yi)[13]) {
             yr[k + 10] = ar + bi;
             yi[k + 10] = ai - br;
         }
+    }
+}
+
+// cos, sin of 2 pi j / 20 and 2 pi j / 30
+constexpr float C20[20] = {
+    1.0f, 0.9510565162951535f, 0.8090169943749475f, 0.5877852522924731f, 0.30901699437494745f,
+    0.0f, -0.30901699437494734f, -0.587785252292473f, -0.8090169943749473f, -0.9510565162951535f,
+    -1.0f, -0.9510565162951538f, -0.8090169943749476f, -0.5877852522924732f, -0.30901699437494756f,
+    0.0f, 0.30901699437494723f, 0.5877852522924729f, 0.8090169943749473f, 0.9510565162951535f};
+constexpr float S20[20] = {
+    0.0f, 0.3090169943749474f, 0.5877852522924731f, 0.8090169943749475f, 0.9510565162951535f, 1.0f,
+    0.9510565162951536f, 0.8090169943749475f, 0.5877852522924732f, 0.3090169943749475f, 0.0f,
+    -0.3090169943749469f, -0.587785252292473f, -0.8090169943749473f, -0.9510565162951535f, -1.0f,
+    -0.9510565162951536f, -0.8090169943749476f, -0.5877852522924734f, -0.3090169943749476f};
+constexpr float C30[30] = {
+    1.0f, 0.9781476007338057f, 0.9135454576426009f, 0.8090169943749475f, 0.6691306063588582f,
+    0.5000000000000001f, 0.30901699437494745f, 0.10452846326765346f, -0.10452846326765333f,
+    -0.30901699437494734f, -0.4999999999999998f, -0.6691306063588579f, -0.8090169943749473f,
+    -0.913545457642601f, -0.9781476007338057f, -1.0f, -0.9781476007338057f, -0.9135454576426009f,
+    -0.8090169943749476f, -0.6691306063588585f, -0.5000000000000004f, -0.30901699437494756f,
+    -0.10452846326765423f, 0.10452846326765299f, 0.30901699437494723f, 0.5000000000000001f,
+    0.6691306063588585f, 0.8090169943749473f, 0.913545457642601f, 0.9781476007338057f};
+constexpr float S30[30] = {
+    0.0f, 0.20791169081775931f, 0.40673664307580015f, 0.5877852522924731f, 0.7431448254773941f,
+    0.8660254037844386f, 0.9510565162951535f, 0.9945218953682733f, 0.9945218953682734f,
+    0.9510565162951536f, 0.8660254037844387f, 0.7431448254773945f, 0.5877852522924732f,
+    0.40673664307580004f, 0.20791169081775931f, 0.0f, -0.20791169081775907f, -0.4067366430758002f,
+    -0.587785252292473f, -0.743144825477394f, -0.8660254037844384f, -0.9510565162951535f,
+    -0.9945218953682733f, -0.9945218953682734f, -0.9510565162951536f, -0.8660254037844386f,
+    -0.743144825477394f, -0.5877852522924734f, -0.40673664307580015f, -0.20791169081775898f};
+
+template <int A> struct TrigTable;
+template <> struct TrigTable<20> { static constexpr const float* c() { return C20; } static constexpr const float* s() { return S20; } };
+template <> struct TrigTable<30> { static constexpr const float* c() { return C30; } static constexpr const float* s() { return S30; } };
+
+// Real A-point DFT for even A (20, 30), bins 0 .. A/2: Y[c] = sum_a x[a] exp(-2 pi i a c / A), by
+// the direct sum folded twice.  With H = A/2, p[a] = x[a] + x[A-a] and q[a] = x[a] - x[A-a]
+// (a = 1 .. H-1),
+//     Re Y[c] = x[0] + (-1)^c x[H] + sum_a p[a] cos(2 pi a c / A),   Im Y[c] = -sum_a q[a] sin(2 pi a c / A);
+// a and H - a have equal cosines for even c and opposite ones for odd c (the sines the other way
+// round), so each sum runs over a < H/2 only, on pe = p[a] + p[H-a], po = p[a] - p[H-a],
+// qe = q[a] - q[H-a], qo = q[a] + q[H-a], plus the middle term a = H/2 when H is even.  All
+// trigonometric factors are literals: (H - 1) / 2 * 2 fused multiply-adds per bin.
+template <int A>
+FC_HD void rdft_even(const float (&x)[A], float (&yr)[A / 2 + 1], float (&yi)[A / 2 + 1]) {
+    static_assert(A % 2 == 0, "rdft_even: A must be even");
+    constexpr int H = A / 2, M = (H - 1) / 2;       // folded terms a = 1 .. M
+    float pe[M + 1], po[M + 1], qe[M + 1], qo[M + 1];
+#pragma unroll
+    for (int a = 1; a <= M; ++a) {
+        const float p1 = x[a] + x[A - a], q1 = x[a] - x[A - a];
+        const float p2 = x[H - a] + x[H + a], q2 = x[H - a] - x[H + a];
+        pe[a] = p1 + p2; po[a] = p1 - p2;
+        qe[a] = q1 - q2; qo[a] = q1 + q2;
+    }
+    const float pm = (H % 2 == 0) ? x[H / 2] + x[A - H / 2] : 0.0f;   // middle term, H even only
+    const float qm = (H % 2 == 0) ? x[H / 2] - x[A - H / 2] : 0.0f;
+    const float s_even = x[0] + x[H], s_odd = x[0] - x[H];
+#pragma unroll
+    for (int c = 0; c <= H; ++c) {
+        float re = (c % 2 == 0) ? s_even : s_odd, im = 0.0f;
+        if (H % 2 == 0) {
+            if (c % 2 == 0) re += (c % 4 == 0) ? pm : -pm;           // cos(pi c / 2)
+            else im += (c % 4 == 1) ? qm : -qm;                       // sin(pi c / 2)
+        }
+#pragma unroll
+        for (int a = 1; a <= M; ++a) {
+            const float cs = TrigTable<A>::c()[(a * c) % A], sn = TrigTable<A>::s()[(a * c) % A];
+            re = fmaf((c % 2 == 0) ? pe[a] : po[a], cs, re);
+            im = fmaf((c % 2 == 0) ? qe[a] : qo[a], sn, im);
+        }
+        yr[c] = re;
+        yi[c] = -im;
     }
 }
 

@@ -1,21 +1,23 @@
-// 400-point front end for gfx950 (the 25 ms window of 16 kHz speech front ends taken as the
-// transform length, e.g. n_fft = 400, hop 160, 80 mels): one wavefront per four consecutive
-// frames, no barriers in the frame loop.
+// Front end for n_fft = 16 A with A = 20, 25, 30 (n_fft = 320, 400, 480: the 20, 25 and 30 ms
+// windows of 16 kHz speech front ends taken as the transform length, e.g. n_fft = 400, hop 160,
+// 80 mels) on gfx950: one wavefront per four consecutive frames, no barriers in the frame loop.
 //
-//   pad / frame / window -> 400-point real DFT (25 x 16) -> |X|^power -> sparse mel filterbank
+//   pad / frame / window -> N-point real DFT (A x 16) -> |X|^power -> sparse mel filterbank
 //
 // Same role as front_2048.h (the stft + abs**power + mel einsum part of librosa.feature.mfcc,
-// /root/reference/src/preprocess.py:134) for n_fft = 400.
+// /root/reference/src/preprocess.py:134) for these n_fft.
 //
-// Frame x[n], n = 16 a + b (a < 25, b < 16); bin k = c + 25 d (c < 25, d < 16):
-//     W_400^(n k) = W_25^(a c) W_400^(b c) W_16^(b d)
-//  step 1  lane (t = lane>>4, b = lane&15) holds the 25 samples a = 0..24 of frame t and computes
-//          the real 25-point DFT over a for c = 0..12 in registers (5 x 5, fc::rdft25)
-//  twiddle Z[b][c] = Y[b][c] W_400^(b c)
+// Frame x[n], n = 16 a + b (a < A, b < 16); bin k = c + A d (c < A, d < 16):
+//     W_N^(n k) = W_A^(a c) W_N^(b c) W_16^(b d)
+//  step 1  lane (t = lane>>4, b = lane&15) holds the A samples a = 0..A-1 of frame t and computes
+//          the real A-point DFT over a for c = 0..A/2 in registers (fc::rdft25: 5 x 5;
+//          fc::rdft_even<20 / 30>: folded direct sums)
+//  twiddle Z[b][c] = Y[b][c] W_N^(b c)
 //  exchange through LDS: column (t, c) = 16 complex, columns 36 floats apart (conflict-free
 //          16-byte reads)
-//  step 2  lane t 13 + c (52 of 64 lanes) reads its column and does the 16-point DFT over b in
-//          registers -> X[c + 25 d]; d >= 8 are the mirror images 400 - k of the columns c > 12
+//  step 2  lane t NC + c (NC = A/2 + 1 columns per frame) reads its column and does the 16-point
+//          DFT over b in registers -> X[c + A d]; d >= 8 are the mirror images N - k of the
+//          columns c > A/2 (for even A the middle column c = A/2 mirrors onto itself)
 //  mel     as in front_pow2.h: lane = (frame, filter) pair, 16 filters per round
 #pragma once
 #include <hip/hip_runtime.h>
@@ -24,29 +26,42 @@
 
 #include "front_pow2.h"
 
-namespace k400 {
-constexpr int N = 400, NB = 201, T = 4, NA = 25, NC = 13;   // NA samples per lane, NC columns per frame
+namespace k16a {
+constexpr int T = 4;                    // frames per wavefront pass
 constexpr int COL = 36;                 // floats per exchange column: 16 complex + 4 floats of padding
-constexpr int REGION = k2048::XCH_FLOATS;
-constexpr int P_STRIDE = 272;           // frame t's power spectrum starts at float 272 t: the bases
-                                        // are 16 floats apart modulo 64, so the 52 lanes of a store
-                                        // (13 consecutive bins per frame) hit 52 different banks
-constexpr int TW_FLOATS = 12 * 16 * 2;  // W_400^(b c), c = 1..12
-static_assert(T * NC * COL <= REGION && T * P_STRIDE <= REGION, "wavefront region too small");
-__host__ __device__ constexpr int p_base(int t) { return P_STRIDE * t; }
+template <int A>
+struct Geo {
+    static_assert(A == 20 || A == 25 || A == 30, "supported: n_fft = 320, 400, 480");
+    static constexpr int N = 16 * A, NB = N / 2 + 1, NA = A, NC = A / 2 + 1;   // NC columns per frame
+    static_assert(T * NC <= 64, "one lane per column");
+    // frame t's power spectrum starts at float P_STRIDE t: the bases are 16 floats apart modulo
+    // 64, so the T NC lanes of a store (NC <= 16 consecutive bins per frame) hit different banks
+    static constexpr int P_STRIDE = (NB + 8 + 47) / 64 * 64 + 16;
+    static constexpr int TW_FLOATS = (NC - 1) * 16 * 2;                          // W_N^(b c), c = 1..NC-1
+    static constexpr int REGION_MIN = T * NC * COL > T * P_STRIDE ? T * NC * COL : T * P_STRIDE;
+    static constexpr int REGION = REGION_MIN > k2048::XCH_FLOATS ? (REGION_MIN + 63) / 64 * 64 : k2048::XCH_FLOATS;
+    static constexpr int p_base(int t) { return P_STRIDE * t; }
+    static constexpr size_t lds_bytes(int waves, int mel_quads, int mel_rounds) {
+        return sizeof(float) * ((size_t)waves * REGION + TW_FLOATS + 4 * (size_t)mel_quads * (64 / T) +
+                                2 * 64 * (size_t)mel_rounds + 4 /* unit counter */);
+    }
+};
+static_assert(Geo<25>::P_STRIDE == 272 && Geo<25>::REGION == k2048::XCH_FLOATS, "n_fft = 400 layout");
 
-constexpr size_t lds_bytes(int waves, int mel_quads, int mel_rounds) {
-    return sizeof(float) * ((size_t)waves * REGION + TW_FLOATS + 4 * (size_t)mel_quads * (64 / T) +
-                            2 * 64 * (size_t)mel_rounds + 4 /* unit counter */);
+template <int A>
+__device__ __forceinline__ void rdft_a(const float (&x)[A], float (&yr)[A / 2 + 1], float (&yi)[A / 2 + 1]) {
+    if constexpr (A == 25) fc::rdft25(x, yr, yi);
+    else fc::rdft_even<A>(x, yr, yi);
 }
+}  // namespace k16a
 
-}  // namespace k400
-
-// Pow2Args with tw1 = W_400^(b c) as [c - 1][b] (12 x 16); w64 and tw128 are unused.
-template <int WAVES, int PW, bool PCM16>
-__global__ __launch_bounds__(WAVES * 64) void k_melspec_400(const Pow2Args a) {
+// Pow2Args with tw1 = W_N^(b c) as [c - 1][b] ((NC - 1) x 16); w64 and tw128 are unused.
+template <int A, int WAVES, int PW, bool PCM16>
+__global__ __launch_bounds__(WAVES * 64) void k_melspec_16a(const Pow2Args a) {
     using namespace k2048;
-    using namespace k400;
+    using namespace k16a;
+    using G = Geo<A>;
+    constexpr int N = G::N, NB = G::NB, NA = G::NA, NC = G::NC, REGION = G::REGION, TW_FLOATS = G::TW_FLOATS;
     constexpr int THREADS = WAVES * 64;
     constexpr int FPR = 64 / T;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -70,7 +85,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_400(const Pow2Args a) {
     __syncthreads();
 
     const int b = lane & 15, tf = lane >> 4;        // step 1: residue and frame of this lane
-    const int col = min(lane, T * NC - 1);          // step 2: column t2 * 13 + c2 (lanes >= 52 idle)
+    const int col = min(lane, T * NC - 1);          // step 2: column t2 * NC + c2 (lanes >= T NC idle)
     const int t2 = col / NC, c2 = col - t2 * NC;
     const bool active2 = lane < T * NC;
     float win[NA];
@@ -78,7 +93,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_400(const Pow2Args a) {
     for (int i = 0; i < NA; ++i) win[i] = a.window[16 * i + b];
     const int xw = (tf * NC * COL) / 2 + b;         // complex index of Z[b][0] of frame tf
     const float* xr = X + col * COL;
-    const int pb = p_base(t2);
+    const int pb = G::p_base(t2);
 
     float runmax = 0.0f;
     int cur_grp = -1;
@@ -141,7 +156,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_400(const Pow2Args a) {
             for (int i = 0; i < NA; ++i) x[i] = 0.0f;
 #pragma unroll 1
             for (int t = 0; t < nvalid; ++t) {
-                kp2::stage_edge_rows(X, a.pcm, tc.soff, PCM16, first + t * a.hop, tc.T, a.reflect, lane, 7);
+                kp2::stage_edge_rows(X, a.pcm, tc.soff, PCM16, first + t * a.hop, tc.T, a.reflect, lane, (N + 63) / 64);
                 if (tf == t) {
 #pragma unroll
                     for (int i = 0; i < NA; ++i) x[i] = X[16 * i + b];
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_400(const Pow2Args a) {
         // ---- step 1: real DFT-25 over a, twiddle, exchange -----------------------------------------
         {
             float yr[NC], yi[NC];
-            fc::rdft25(x, yr, yi);
+            rdft_a<A>(x, yr, yi);
             float2 tw[NC];
 #pragma unroll
             for (int c = 1; c < NC; ++c) tw[c] = tw_l[(c - 1) * 16 + b];
@@ -176,15 +191,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_400(const Pow2Args a) {
         fc::cfft16(dr, di);
 
         // ---- power spectra -> LDS (natural bin order per frame) --------------------------------------
-        // bin c2 + 25 d for d < 8; d >= 8 is the mirror image 25 (16 - d) - c2 (for c2 = 0 only
-        // d = 8, bin 200: the others repeat bins 25 d)
+        // bin c2 + A d for d < 8; d >= 8 is the mirror image A (16 - d) - c2 (for c2 = 0 only
+        // d = 8, bin N/2: the others repeat bins A d; for even A the column c2 = A/2 mirrors onto
+        // its own bins, so its d >= 8 are skipped)
         if (active2) {
+            const bool mirrors = c2 != 0 && (A % 2 != 0 || c2 != A / 2);
 #pragma unroll
             for (int d = 0; d < 16; ++d) {
                 const float re = dr[fc::cfft16_pos(d)], im = di[fc::cfft16_pos(d)];
                 const float pw = apply_power<PW>(re * re + im * im, a.pw_mode, a.half_power);
-                if (d < 8) X[pb + c2 + 25 * d] = pw;
-                else if (d == 8 || c2 != 0) X[pb + 25 * (16 - d) - c2] = pw;
+                if (d < 8) X[pb + c2 + A * d] = pw;
+                else if ((d == 8 && c2 == 0) || mirrors) X[pb + A * (16 - d) - c2] = pw;
             }
         }
 
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_400(const Pow2Args a) {
             for (int t = 0; t < T; ++t) {
                 if (t < nvalid) {
                     float* so = a.spec_out + (row0 + t) * NB;
-                    for (int k = lane; k < NB; k += 64) so[k] = X[p_base(t) + k];
+                    for (int k = lane; k < NB; k += 64) so[k] = X[G::p_base(t) + k];
                 }
             }
         }

@@ -602,15 +602,17 @@ Pow2Fn pow2_pick(bool pw2, bool pcm16) {
     if (pw2) return pcm16 ? k_melspec_pow2<L, W, 0, true> : k_melspec_pow2<L, W, 0, false>;
     return pcm16 ? k_melspec_pow2<L, W, 1, true> : k_melspec_pow2<L, W, 1, false>;
 }
-template <int W>
-Pow2Fn k400_pick(bool pw2, bool pcm16) {
-    if (pw2) return pcm16 ? k_melspec_400<W, 0, true> : k_melspec_400<W, 0, false>;
-    return pcm16 ? k_melspec_400<W, 1, true> : k_melspec_400<W, 1, false>;
+template <int A, int W>
+Pow2Fn k16a_pick(bool pw2, bool pcm16) {
+    if (pw2) return pcm16 ? k_melspec_16a<A, W, 0, true> : k_melspec_16a<A, W, 0, false>;
+    return pcm16 ? k_melspec_16a<A, W, 1, true> : k_melspec_16a<A, W, 1, false>;
 }
-// small_fft: 8, 9, 10 for the power-of-two kernels; 400 stands for the 400-point kernel
+// small_fft: 8, 9, 10 for the power-of-two kernels; 320, 400, 480 for the 16 A kernels (front_400.h)
 Pow2Fn pow2_kernel(const mfcc_plan* p, bool pcm16) {
     const bool pw2 = p->r.c.power == 2.0f;
-    if (p->small_fft == 400) return p->p2_waves == 16 ? k400_pick<16>(pw2, pcm16) : k400_pick<8>(pw2, pcm16);
+    if (p->small_fft == 320) return p->p2_waves == 16 ? k16a_pick<20, 16>(pw2, pcm16) : k16a_pick<20, 8>(pw2, pcm16);
+    if (p->small_fft == 400) return p->p2_waves == 16 ? k16a_pick<25, 16>(pw2, pcm16) : k16a_pick<25, 8>(pw2, pcm16);
+    if (p->small_fft == 480) return p->p2_waves == 16 ? k16a_pick<30, 16>(pw2, pcm16) : k16a_pick<30, 8>(pw2, pcm16);
     if (p->small_fft == 8) return p->p2_waves == 16 ? pow2_pick<8, 16>(pw2, pcm16) : pow2_pick<8, 8>(pw2, pcm16);
     if (p->small_fft == 9) return p->p2_waves == 16 ? pow2_pick<9, 16>(pw2, pcm16) : pow2_pick<9, 8>(pw2, pcm16);
     return p->p2_waves == 16 ? pow2_pick<10, 16>(pw2, pcm16) : pow2_pick<10, 8>(pw2, pcm16);
@@ -698,24 +700,30 @@ bool build_pow2_tables(mfcc_plan* p, const std::vector<float>& basis, std::vecto
     return true;
 }
 
-// Tables of the 400-point front end (front_400.h); false: the dense-DFT kernel takes over.
-bool build_400_tables(mfcc_plan* p, const std::vector<float>& basis, std::vector<float2>& tw1,
+// Tables of the n_fft = 16 A front ends (front_400.h); false: the dense-DFT kernel takes over.
+template <int A>
+bool build_16a_tables(mfcc_plan* p, const std::vector<float>& basis, std::vector<float2>& tw1,
                       std::vector<float4>& melw, std::vector<uint2>& pairs) {
+    using G = k16a::Geo<A>;
     const double PI = 3.14159265358979323846;
-    tw1.assign(12 * 16, make_float2(1.0f, 0.0f));
-    for (int c = 1; c <= 12; ++c)
+    tw1.assign((size_t)(G::NC - 1) * 16, make_float2(1.0f, 0.0f));
+    for (int c = 1; c < G::NC; ++c)
         for (int b = 0; b < 16; ++b) {
-            const double ang = -2.0 * PI * (double)(b * c) / 400.0;
+            const double ang = -2.0 * PI * (double)(b * c) / (double)G::N;
             tw1[(size_t)(c - 1) * 16 + b] = make_float2((float)std::cos(ang), (float)std::sin(ang));
         }
-    if (!build_pair_mel(p, basis, k400::T, [](int t) { return k400::p_base(t); }, k400::P_STRIDE, melw, pairs,
+    if (!build_pair_mel(p, basis, k16a::T, [](int t) { return G::p_base(t); }, G::P_STRIDE, melw, pairs,
                         &p->p2_quads, &p->p2_rounds))
         return false;
     p->p2_waves = 0;
+    const char* force = std::getenv("MFCC_HIP_P2_WAVES");      // experiments: 8 or 16
     for (int w : {16, 8})
-        if (k400::lds_bytes(w, p->p2_quads, p->p2_rounds) <= (size_t)k2048::LDS_LIMIT) { p->p2_waves = w; break; }
+        if ((!force || std::atoi(force) == w) && G::lds_bytes(w, p->p2_quads, p->p2_rounds) <= (size_t)k2048::LDS_LIMIT) {
+            p->p2_waves = w;
+            break;
+        }
     if (!p->p2_waves) return false;
-    p->p2_lds_bytes = k400::lds_bytes(p->p2_waves, p->p2_quads, p->p2_rounds);
+    p->p2_lds_bytes = G::lds_bytes(p->p2_waves, p->p2_quads, p->p2_rounds);
     return true;
 }
 
@@ -893,12 +901,14 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         for (size_t i = 0; i < jobs.size(); ++i)
             jobs[i] = make_int2(4 * p->mj.at[i], 4 * (k2048::MCELL_OFF + p->mj.cell[i]) | (p->mj.cont[i] ? 1 : 0));
     }
-    // n_fft 256 / 400 / 512 / 1024: the in-register FFT kernels (MFCC_HIP_DENSE_DFT=1 keeps the dense-DFT one)
+    // n_fft 256 / 320 / 400 / 480 / 512 / 1024: the in-register FFT kernels (MFCC_HIP_DENSE_DFT=1 keeps the dense-DFT one)
     std::vector<float2> p2_tw1;
     std::vector<float4> p2_melw;
     std::vector<uint2> p2_pairs;
     if (!std::getenv("MFCC_HIP_DENSE_DFT")) {
-        if (r.c.n_fft == 400 && build_400_tables(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 400;
+        if (r.c.n_fft == 320 && build_16a_tables<20>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 320;
+        if (r.c.n_fft == 400 && build_16a_tables<25>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 400;
+        if (r.c.n_fft == 480 && build_16a_tables<30>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 480;
         if (r.c.n_fft == 256 && build_pow2_tables<8>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 8;
         if (r.c.n_fft == 512 && build_pow2_tables<9>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 9;
         if (r.c.n_fft == 1024 && build_pow2_tables<10>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 10;
@@ -1053,7 +1063,7 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
         pa.reflect = plan->r.c.pad_mode == MFCC_PAD_REFLECT;
         pa.pw_mode = plan->r.c.power == 2.0f ? 0 : (plan->r.c.power == 1.0f ? 1 : 2);
         pa.half_power = 0.5f * plan->r.c.power;
-        const int passes_per_tile = plan->small_fft == 400 ? 4 : (1 << plan->small_fft) / 128;
+        const int passes_per_tile = plan->small_fft >= 320 ? TILE_FRAMES / k16a::T : (1 << plan->small_fft) / 128;
         const int64_t wg_needed = (L.ub_tiles * passes_per_tile + plan->p2_waves - 1) / plan->p2_waves;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(wg_needed, plan->n_cu));
         if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
@@ -1283,7 +1293,9 @@ int mfcc_workspace_status(const void* d_workspace, void* stream) {
 const char* mfcc_plan_front_kernel(const mfcc_plan* plan) {
     if (!plan) return nullptr;
     if (plan->fast2048) return "fft2048";
+    if (plan->small_fft == 320) return "fft320";
     if (plan->small_fft == 400) return "fft400";
+    if (plan->small_fft == 480) return "fft480";
     if (plan->small_fft == 8) return "fft256";
     if (plan->small_fft == 9) return "fft512";
     if (plan->small_fft == 10) return "fft1024";

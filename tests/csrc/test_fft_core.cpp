@@ -46,11 +46,31 @@ static double check_rdft25() {
     return worst;
 }
 
+template <int A>
+static double check_rdft_even() {
+    const double PI = 3.14159265358979323846;
+    double worst = 0.0;
+    for (int trial = 0; trial < 50; ++trial) {
+        float x[A], yr[A / 2 + 1], yi[A / 2 + 1]; double xd[A];
+        for (int n = 0; n < A; ++n) xd[n] = x[n] = (float)rand() / RAND_MAX - 0.5f;
+        fc::rdft_even<A>(x, yr, yi);
+        for (int k = 0; k <= A / 2; ++k) {
+            double sr = 0, si = 0;
+            for (int n = 0; n < A; ++n) { sr += xd[n] * cos(2 * PI * n * k / A); si -= xd[n] * sin(2 * PI * n * k / A); }
+            worst = fmax(worst, fabs(sr - yr[k]));
+            worst = fmax(worst, fabs(si - yi[k]));
+        }
+    }
+    return worst;
+}
+
 int main() {
     const double PI = 3.14159265358979323846;
     double worst = 0.0;
     srand(7);
     worst = fmax(worst, check_rdft25());
+    worst = fmax(worst, check_rdft_even<20>());
+    worst = fmax(worst, check_rdft_even<30>());
     worst = fmax(worst, check_rdft_cols<2>());
     worst = fmax(worst, check_rdft_cols<4>());
     worst = fmax(worst, check_rdft_cols<8>());

@@ -81,7 +81,10 @@ def test_reference_default_one_utterance(S):
     dict(n_fft=512, hop_length=128, pad_mode="reflect", n_mels=64),
     dict(n_fft=400, hop_length=160, n_mels=80, sr=16000, center=False),
     dict(n_fft=254, hop_length=77, n_mels=20, sr=8000),
-    dict(n_fft=320, hop_length=160, n_mels=40, sr=16000),          # dense-DFT kernel
+    dict(n_fft=320, hop_length=160, n_mels=40, sr=16000),          # 20 x 16 in-register kernel
+    dict(n_fft=480, hop_length=160, n_mels=80, sr=16000),          # 30 x 16 in-register kernel
+    dict(n_fft=480, hop_length=240, n_mels=128, sr=22050, pad_mode="reflect"),
+    dict(n_fft=640, hop_length=160, n_mels=40, sr=16000),          # dense-DFT kernel
     dict(n_fft=512, hop_length=160, n_mels=10, sr=16000),          # wide filters on the 512-point kernel
     dict(n_fft=1024, hop_length=256, n_mels=256, sr=44100),        # 16 mel rounds of 32 filters
     dict(n_fft=400, hop_length=160, n_mels=1, sr=16000),
@@ -110,6 +113,8 @@ def test_melspectrogram_parity(S, kw):
     dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
     dict(n_fft=1024, hop_length=256, n_mfcc=13, n_mels=80),
     dict(n_fft=256, hop_length=80, n_mfcc=13, n_mels=40, sr=8000),
+    dict(n_fft=480, hop_length=160, n_mfcc=13, n_mels=80, sr=16000),
+    dict(n_fft=320, hop_length=160, n_mfcc=13, n_mels=40, sr=16000),
 ])
 def test_mfcc_parity(S, kw):
     y = speech_like(52001, seed=5)
@@ -120,7 +125,7 @@ def test_mfcc_parity(S, kw):
     np.testing.assert_allclose(got, want, rtol=0, atol=DB_TOL)
 
 
-@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160), (512, 128), (1024, 256), (256, 64)])
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160), (512, 128), (1024, 256), (256, 64), (480, 160), (320, 80)])
 def test_spectrogram_parity(S, n_fft, hop):
     y = speech_like(30000, seed=4)
     want = np.abs(R.stft(y, n_fft=n_fft, hop_length=hop)) ** 2

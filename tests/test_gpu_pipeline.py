@@ -161,7 +161,9 @@ def test_int16_pcm_ingest_is_bit_identical(gpu, kw):
     (dict(n_fft=1024, hop_length=256), "fft1024"),
     (dict(n_fft=256, hop_length=80, n_mels=40, sr=8000), "fft256"),
     (dict(n_fft=400, hop_length=160, n_mels=80, sr=16000), "fft400"),
-    (dict(n_fft=320, hop_length=160, n_mels=40, sr=16000), "dense_dft"),
+    (dict(n_fft=320, hop_length=160, n_mels=40, sr=16000), "fft320"),
+    (dict(n_fft=480, hop_length=160, n_mels=80, sr=16000), "fft480"),
+    (dict(n_fft=640, hop_length=160, n_mels=80, sr=16000), "dense_dft"),
 ])
 def test_front_kernel_selection(gpu, kw, name):
     import speech_to_text_amd as S
@@ -181,6 +183,11 @@ def test_front_kernel_selection(gpu, kw, name):
     dict(n_fft=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
     dict(n_fft=400, hop_length=100, n_mels=128, n_mfcc=20, sr=16000, pad_mode="reflect", window="hamming"),
     dict(n_fft=400, hop_length=400, n_mels=23, n_mfcc=13, sr=16000, center=False, power=1.0),
+    dict(n_fft=480, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
+    dict(n_fft=480, hop_length=120, n_mels=128, n_mfcc=20, sr=16000, pad_mode="reflect", window="hamming"),
+    dict(n_fft=480, hop_length=480, n_mels=23, n_mfcc=13, sr=16000, center=False, power=1.0),
+    dict(n_fft=320, hop_length=160, n_mels=40, n_mfcc=13, sr=16000),
+    dict(n_fft=320, hop_length=77, n_mels=80, n_mfcc=20, sr=16000, pad_mode="reflect"),
 ])
 def test_fft_and_dense_dft_kernels_agree(gpu, kw, monkeypatch):
     """The in-register FFT kernel and the dense-DFT kernel are independent implementations of the

@@ -24,7 +24,9 @@ which = %r
 cfg = {"ref": S.MfccConfig.reference_default(),
        "asr512": S.make_config(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13),
        "asr400": S.make_config(sr=16000, n_fft=400, hop_length=160, n_mels=80, n_mfcc=13),
-       "fft1024": S.make_config(sr=16000, n_fft=1024, hop_length=256, n_mels=80, n_mfcc=13)}[which]
+       "fft1024": S.make_config(sr=16000, n_fft=1024, hop_length=256, n_mels=80, n_mfcc=13),
+       "asr480": S.make_config(sr=16000, n_fft=480, hop_length=160, n_mels=80, n_mfcc=13),
+       "asr320": S.make_config(sr=16000, n_fft=320, hop_length=160, n_mels=80, n_mfcc=13)}[which]
 dev = torch.device('cuda', 0)
 pcm, so = make_batch(%f, 1234, dev)
 r = run(cfg, pcm, so, steps=20, warmup=3)
