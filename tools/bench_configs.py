@@ -9,7 +9,8 @@ config 3  1000 h: the 10 h resident batch looped 100 times, HIP-event kernel tim
 config 4  ASR front end: sr 16000, hop 160, 80 mels, 13 MFCC with n_fft = 400 (25 x 16 in-register
           DFT kernel) and with n_fft = 512 / win_length = 400 (the 400-sample window zero-padded
           to a 512-point FFT; in-register FFT kernel), + global CMVN (accumulate, apply)
-extra     n_fft = 480 (30 ms), which no in-register kernel covers: the dense-DFT (MFMA) kernel
+extra     n_fft = 480 (30 ms) and 320 (20 ms): the 30 x 16 and 20 x 16 in-register kernels; n_fft = 640,
+          which no in-register kernel covers: the dense-DFT (MFMA) kernel
 config 5  long utterances U(30, 60) s, one of them silent but for a click
 
 Each entry: audio-hours/s from wall time over whole steps (synchronised), per-kernel HIP-event
@@ -105,7 +106,11 @@ def main():
     asr512 = S.make_config(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13)
     results["config4_nfft512_win400_cmvn"] = run(asr512, pcm, so, steps=10, warmup=2, with_cmvn=True)
     asr480 = S.make_config(sr=16000, n_fft=480, hop_length=160, n_mels=80, n_mfcc=13)
-    results["extra_nfft480_dense_dft"] = run(asr480, pcm, so, steps=5, warmup=2)
+    results["extra_nfft480"] = run(asr480, pcm, so, steps=10, warmup=2)
+    asr320 = S.make_config(sr=16000, n_fft=320, hop_length=160, n_mels=80, n_mfcc=13)
+    results["extra_nfft320"] = run(asr320, pcm, so, steps=10, warmup=2)
+    asr640 = S.make_config(sr=16000, n_fft=640, hop_length=160, n_mels=80, n_mfcc=13)
+    results["extra_nfft640_dense_dft"] = run(asr640, pcm, so, steps=5, warmup=2)
     del pcm
 
     pcm5, so5 = make_batch(args.hours, 5, dev, lo_s=30.0, hi_s=60.0)
