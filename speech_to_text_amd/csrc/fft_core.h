@@ -59,12 +59,8 @@ constexpr int cfft16_pos(int k) { return (k >> 2) + 4 * (k & 3); }
 
 // 16-point complex DFT in place.  Input: re[n], im[n] in natural order.  Output: bin k is at
 // index cfft16_pos(k) (base-4 digit reversal).
-FC_HD void cfft16(float (&re)[16], float (&im)[16]) {
-    // Pass 1: for each n1, 4-point DFT over n2 of x[n1 + 4 n2]; t[n1][k2] lands at n1 + 4 k2.
-#pragma unroll
-    for (int n1 = 0; n1 < 4; ++n1)
-        bfly4(re[n1], im[n1], re[n1 + 4], im[n1 + 4], re[n1 + 8], im[n1 + 8], re[n1 + 12],
-              im[n1 + 12]);
+// Twiddles and second pass of cfft16, on the outputs of its first pass.
+FC_HD void cfft16_tail(float (&re)[16], float (&im)[16]) {
     // Twiddles W16^(n1 k2) at index n1 + 4 k2 (n1, k2 in 1..3).
     cmul(re[5], im[5], W16_1r, W16_1i);     // n1=1,k2=1
     cmul(re[6], im[6], W16_2r, W16_2i);     // n1=2,k2=1
@@ -82,6 +78,39 @@ FC_HD void cfft16(float (&re)[16], float (&im)[16]) {
     for (int k2 = 0; k2 < 4; ++k2)
         bfly4(re[4 * k2], im[4 * k2], re[4 * k2 + 1], im[4 * k2 + 1], re[4 * k2 + 2],
               im[4 * k2 + 2], re[4 * k2 + 3], im[4 * k2 + 3]);
+}
+
+FC_HD void cfft16(float (&re)[16], float (&im)[16]) {
+    // Pass 1: for each n1, 4-point DFT over n2 of x[n1 + 4 n2]; t[n1][k2] lands at n1 + 4 k2.
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1)
+        bfly4(re[n1], im[n1], re[n1 + 4], im[n1 + 4], re[n1 + 8], im[n1 + 8], re[n1 + 12],
+              im[n1 + 12]);
+    cfft16_tail(re, im);
+}
+
+// cfft16 of z[m] = x[2m] w[2m] + i x[2m+1] w[2m+1] (a windowed real sequence packed in pairs), with
+// the window multiplications folded into the first pass: a w_a +- c w_c is one multiplication and
+// two fused multiply-adds instead of two multiplications and two additions.
+FC_HD void cfft16_windowed(const float (&x)[32], const float (&w)[32], float (&re)[16], float (&im)[16]) {
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) {
+        float s[2][4];                       // [re / im][x0+x2, x0-x2, x1+x3, x1-x3]
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ia = 2 * n1 + c, ib = 2 * (n1 + 4) + c, ic = 2 * (n1 + 8) + c, id = 2 * (n1 + 12) + c;
+            const float tc = x[ic] * w[ic], td = x[id] * w[id];
+            s[c][0] = fmaf(x[ia], w[ia], tc);
+            s[c][1] = fmaf(x[ia], w[ia], -tc);
+            s[c][2] = fmaf(x[ib], w[ib], td);
+            s[c][3] = fmaf(x[ib], w[ib], -td);
+        }
+        re[n1] = s[0][0] + s[0][2];      im[n1] = s[1][0] + s[1][2];            // X0
+        re[n1 + 8] = s[0][0] - s[0][2];  im[n1 + 8] = s[1][0] - s[1][2];        // X2
+        re[n1 + 4] = s[0][1] + s[1][3];  im[n1 + 4] = s[1][1] - s[0][3];        // X1 = (x0-x2) - i (x1-x3)
+        re[n1 + 12] = s[0][1] - s[1][3]; im[n1 + 12] = s[1][1] + s[0][3];       // X3 = (x0-x2) + i (x1-x3)
+    }
+    cfft16_tail(re, im);
 }
 
 // DFT of a real 32-point sequence r[0..31].

@@ -6,17 +6,18 @@
 //   n_fft = 2048 (/root/reference/src/preprocess.py:134 uses 128) -- all tables in LDS, 16
 //   wavefronts per workgroup drawing the frames of one run from one counter.
 //
-// The arithmetic is that of k_melspec_2048 (same helpers, same order of operations: results are
-// bit-identical); the frame loop is straight-line code apart from the edge-frame and
+// The arithmetic is that of k_melspec_2048 (same helpers, same order of operations) except that
+// the window multiplications are fused into the first butterflies (fc::cfft16_windowed: one
+// rounding fewer per sample); the frame loop is straight-line code apart from the edge-frame and
 // tile / utterance changes.
 #pragma once
 #include "front_2048.h"
 
 namespace k2048 {
-// LDS bytes: tables (step-1 twiddles, step-2 twiddles, window, mel weights, one uint4 of job
-// descriptors per lane, slot counter), then one exchange region per wavefront.
+// LDS bytes: tables (step-1 twiddles, step-2 twiddles, window, mel weights, slot counter), then one
+// exchange region per wavefront.
 constexpr size_t fast_lds_bytes(int waves, int n_jobs) {
-    return sizeof(float) * ((size_t)TW1_FLOATS + W64_FLOATS + WIN_FLOATS + (size_t)n_jobs * MEL_J * 64 * 4 + 64 * 4 + 16 +
+    return sizeof(float) * ((size_t)TW1_FLOATS + W64_FLOATS + WIN_FLOATS + (size_t)n_jobs * MEL_J * 64 * 4 + 16 +
                             (size_t)waves * XCH_FLOATS);
 }
 }  // namespace k2048
@@ -24,7 +25,11 @@ constexpr size_t fast_lds_bytes(int waves, int n_jobs) {
 // PCM16: the input is int16 PCM.
 // (Measured and dropped: requesting the next frame's samples before the mel stage of the current
 // one -- 126 registers, no spills, 1 % slower; storing a frame's outputs at the top of the next
-// frame, after its loads, so that the loads are not queued behind the stores -- no change.)
+// frame, after its loads, so that the loads are not queued behind the stores -- no change; writing
+// column 0's outputs from its four lanes directly, without the DPP spreading -- 2 % slower.)
+#ifndef MFCC_FAST_WINFOLD
+#define MFCC_FAST_WINFOLD 1
+#endif
 template <int WAVES, bool PCM16>
 __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArgs a) {
     using namespace k2048;
@@ -39,8 +44,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
     float2* w64_l = reinterpret_cast<float2*>(lds + TW1_FLOATS);
     float4* win_l = reinterpret_cast<float4*>(lds + TW1_FLOATS + W64_FLOATS);
     float4* melw_l = reinterpret_cast<float4*>(lds + TW1_FLOATS + W64_FLOATS + WIN_FLOATS);
-    uint4* jobs_l = reinterpret_cast<uint4*>(melw_l + NJ * MEL_J * 64);
-    int* run_ctr = reinterpret_cast<int*>(jobs_l + 64);
+    int* run_ctr = reinterpret_cast<int*>(melw_l + NJ * MEL_J * 64);
     float* regions = reinterpret_cast<float*>(run_ctr + 16);
     float* X = regions + wave * XCH_FLOATS;
     float2* X2 = reinterpret_cast<float2*>(X);
@@ -51,13 +55,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
         // W_64^(m kb), m = 1..15, at slot m - 1 of row kb: eight aligned 16-byte reads per row
         const int m = tid & 15;
         w64_l[(tid >> 4) * W64_STRIDE + (m ? m - 1 : 15)] = m ? a.w64[tid] : make_float2(0.0f, 0.0f);
-        uint32_t pk[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int2 jb = a.mel_jobs[j * 64 + tid];
-            pk[j] = (uint32_t)jb.x | ((uint32_t)jb.y << 16);
-        }
-        jobs_l[tid] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     }
     // window quads: float4 (j, lane) = w[lane + 64 (4 j + c)], c = 0..3
     for (int i = tid; i < 512; i += THREADS) {
@@ -121,6 +118,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
         }
     };
 
+    // This lane's four mel jobs, decoded once: where each job's 12 power values start, which cell
+    // takes the chain's sum so far, and whether the job continues the previous job's chain (as a
+    // factor 1 or 0 on the running sum) -- 12 registers instead of a read and its decoding per frame.
+    const float4* job_src[NJ];
+    float* job_cell[NJ];
+    float job_cont[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int2 jb = a.mel_jobs[j * 64 + lane];
+        job_src[j] = reinterpret_cast<const float4*>(reinterpret_cast<char*>(X) + jb.x);
+        job_cell[j] = reinterpret_cast<float*>(reinterpret_cast<char*>(X) + (jb.y & ~3));
+        job_cont[j] = (jb.y & 1) ? 1.0f : 0.0f;
+    }
+
     // outputs of one frame: filter f = cell row 0 (f < 64), rows 1 + 2 (f >= 64); coalesced stores
     const float* cells = X + MCELL_OFF + lane;
     auto collect = [&](int64_t out_row) {
@@ -165,17 +176,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
         }
         const int64_t row = tc.row0 + (t - tc.f0);
 
-        // ---- samples, window ----------------------------------------------------------------------
-        // (the windowed frame replaces the samples in place: smp is the only 32-register array
-        // alive at this point)
-        {
-            if (!interior) {
-                stage_edge_frame(X, a.pcm, tc.soff, PCM16, t * a.hop - a.pad, tc.T, a.reflect, lane);
+        // ---- samples, window, step 1: real DFT-32 over n2, twiddle, exchange -------------------------
+        if (!interior) {
+            stage_edge_frame(X, a.pcm, tc.soff, PCM16, t * a.hop - a.pad, tc.T, a.reflect, lane);
 #pragma unroll
-                for (int n2 = 0; n2 < 32; ++n2) smp[n2] = X[lane + 64 * n2];
+            for (int n2 = 0; n2 < 32; ++n2) smp[n2] = X[lane + 64 * n2];
 #pragma unroll 1
-                for (int i = lane; i < XCH_FLOATS; i += 64) X[i] = 0.0f;
-            }
+            for (int i = lane; i < XCH_FLOATS; i += 64) X[i] = 0.0f;
+        }
+        {
             float wv[32];
             const float4* wq = win_l + lane;
 #pragma unroll
@@ -186,20 +195,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
             __builtin_amdgcn_sched_barrier(0);
             if (PCM16 && interior) {
 #pragma unroll
-                for (int n2 = 0; n2 < 32; ++n2)
-                    smp[n2] = (PCM16_SCALE * (float)__builtin_bit_cast(int, smp[n2])) * wv[n2];
-            } else {
-#pragma unroll
-                for (int n2 = 0; n2 < 32; ++n2) smp[n2] *= wv[n2];
+                for (int n2 = 0; n2 < 32; ++n2) smp[n2] = PCM16_SCALE * (float)__builtin_bit_cast(int, smp[n2]);
             }
-        }
-
-        // ---- step 1: real DFT-32 over n2, twiddle, exchange ------------------------------------
-        {
             float zr[16], zi[16];
+#if MFCC_FAST_WINFOLD
+            // the window multiplications are folded into the first butterflies
+            fc::cfft16_windowed(smp, wv, zr, zi);
+#else
 #pragma unroll
-            for (int m = 0; m < 16; ++m) { zr[m] = smp[2 * m]; zi[m] = smp[2 * m + 1]; }
+            for (int m = 0; m < 16; ++m) { zr[m] = smp[2 * m] * wv[2 * m]; zi[m] = smp[2 * m + 1] * wv[2 * m + 1]; }
             fc::cfft16(zr, zi);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             float2 tw[16];
 #pragma unroll
@@ -279,7 +285,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
             }
         }
         X[MCELL_OFF + 64 * 2 + lane] = 0.0f;       // cell row 2: second chains, absent for most filters
-        const uint4 jq = jobs_l[lane];
         {
             const float2* S = reinterpret_cast<const float2*>(X + SPECIAL_OFF);
             const float2 cj = S[sj];
@@ -298,15 +303,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
         // ---- sparse mel filterbank: four jobs per lane (see front_2048.h) -------------------------
         {
             const float4* wp = melw_l + lane;
-            char* Xb = reinterpret_cast<char*>(X);
-            const uint32_t jobr[NJ] = {jq.x, jq.y, jq.z, jq.w};
             float chain = 0.0f;
 #pragma unroll
             for (int j = 0; j < NJ; j += MEL_BATCH) {
                 float4 w[MEL_BATCH][MEL_J], v[MEL_BATCH][MEL_J];
 #pragma unroll
                 for (int u = 0; u < MEL_BATCH; ++u) {
-                    const float4* pp = reinterpret_cast<const float4*>(Xb + (jobr[j + u] & 0xffffu));
+                    const float4* pp = job_src[j + u];
 #pragma unroll
                     for (int i = 0; i < MEL_J; ++i) {
                         w[u][i] = wp[((j + u) * MEL_J + i) * 64];
@@ -325,8 +328,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
                         acc1 = fmaf(w[u][i].w, v[u][i].w, acc1);
                     }
                     const float part = acc0 + acc1;
-                    chain = (jobr[j + u] & 0x10000u) ? chain + part : part;
-                    *reinterpret_cast<float*>(Xb + ((jobr[j + u] >> 16) & ~3u)) = chain;
+                    chain = fmaf(chain, job_cont[j + u], part);      // chain + part, or part alone
+                    *job_cell[j + u] = chain;
                 }
             }
             collect(row);

@@ -80,6 +80,14 @@ int main() {
             xr[n] = re[n] = (float)rand() / RAND_MAX - 0.5f;
             xi[n] = im[n] = (float)rand() / RAND_MAX - 0.5f;
         }
+        {   // the windowed form equals cfft16 of the windowed, pair-packed sequence
+            float x[32], w[32], wr[16], wi[16], zr[16], zi[16];
+            for (int n = 0; n < 32; ++n) { x[n] = (float)rand() / RAND_MAX - 0.5f; w[n] = (float)rand() / RAND_MAX; }
+            for (int m = 0; m < 16; ++m) { zr[m] = x[2 * m] * w[2 * m]; zi[m] = x[2 * m + 1] * w[2 * m + 1]; }
+            fc::cfft16(zr, zi);
+            fc::cfft16_windowed(x, w, wr, wi);
+            for (int k = 0; k < 16; ++k) { worst = fmax(worst, fabs(zr[k] - wr[k])); worst = fmax(worst, fabs(zi[k] - wi[k])); }
+        }
         fc::cfft16(re, im);
         for (int k = 0; k < 16; ++k) {
             double sr = 0, si = 0;
