@@ -268,7 +268,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # Under a launcher (torch.distributed.run or this script's own) the process group is set up even
+    # for one rank, so that the N = 1 line of a scaling run takes the same path as N > 1.
+    if world > 1 or "WORLD_SIZE" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
@@ -321,8 +323,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    hours_per_step = world * total_samples / SR / 3600.0 if world == 1 else None
-    if world > 1:
+    hours_per_step = total_samples / SR / 3600.0
+    if dist is not None:
         h = torch.tensor([total_samples / SR / 3600.0], dtype=torch.float64, device=device)
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
         hours_per_step = float(h.item())

@@ -370,3 +370,28 @@ def test_timing_history_and_per_stream_workspaces(gpu):
     torch.cuda.synchronize()
     assert all(torch.equal(o, other) for o in outs)
     plan.close()
+
+
+def test_bench_under_torchrun_initialises_rccl(gpu):
+    """The driver's launch form for a scaling run, `python -m torch.distributed.run
+    --nproc-per-node N bench.py --gpus N`, at the N this box allows (1): the rank sets up its
+    process group with the nccl backend (RCCL), runs the barriers and the max / sum all-reduces of
+    the N > 1 path on the GPU, and prints one line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_REHEARSAL")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", str(root / "bench.py"), "--gpus", "1",
+                        "--steps", "5", "--warmup", "2", "--hours", "0.5", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
