@@ -132,7 +132,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
     int* run_ctr = reinterpret_cast<int*>(pairs_l + a.mel_rounds * 64);
 
     for (int i = tid; i < WAVES * REGION; i += THREADS) lds[i] = 0.0f;
-    if (tid < 64) w64_l[(tid >> 4) * W64_STRIDE + (tid & 15)] = a.w64[tid];
+    // W_64^(m kb), m = 1..15, at slot m - 1 of row kb (m = 0 is 1 and never read): the eight
+    // 16-byte reads of a row then carry only used values and stay ds_read_b128
+    if (tid < 64) {
+        const int m = tid & 15;
+        w64_l[(tid >> 4) * W64_STRIDE + (m ? m - 1 : 15)] = m ? a.w64[tid] : make_float2(0.0f, 0.0f);
+    }
     for (int i = tid; i < a.mel_quads * FPR; i += THREADS) melw_l[i] = a.melw[i];
     for (int i = tid; i < a.mel_rounds * 64; i += THREADS) pairs_l[i] = a.mel_pairs[i];
     if (tid == 0) *run_ctr = 0;
@@ -279,11 +284,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
                 const float4 v = *reinterpret_cast<const float4*>(X + (xr_base ^ (4 * j)));
                 dr[2 * j] = v.x; di[2 * j] = v.y; dr[2 * j + 1] = v.z; di[2 * j + 1] = v.w;
             }
-            const float4* wsrc = reinterpret_cast<const float4*>(w64_l + kb * W64_STRIDE);
+            const float4* wsrc = reinterpret_cast<const float4*>(
+                __builtin_assume_aligned(reinterpret_cast<const char*>(w64_l) + kb * (W64_STRIDE * 8), 16));
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float4 v = wsrc[j];
-                w6[2 * j] = make_float2(v.x, v.y); w6[2 * j + 1] = make_float2(v.z, v.w);
+                w6[2 * j + 1] = make_float2(v.x, v.y);
+                if (j < 7) w6[2 * j + 2] = make_float2(v.z, v.w);
             }
             __builtin_amdgcn_sched_barrier(0);   // all exchange + twiddle reads in flight
             quad_fmac8<2>(dr, sgn1); quad_fmac8<2>(dr + 8, sgn1);
