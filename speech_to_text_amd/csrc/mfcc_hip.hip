@@ -59,8 +59,8 @@ __global__ __launch_bounds__(1024) void k_prepare_scan(const int64_t* __restrict
                                                        int n_utts, int32_t* __restrict__ tile_off,
                                                        uint32_t* __restrict__ gmax,
                                                        WsHeader* __restrict__ hdr) {
-    __shared__ int32_t part[1024];
-    const int tid = threadIdx.x;
+    __shared__ int32_t wave_sum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = (n_utts + 1023) / 1024;
     const int lo = min(tid * seg, n_utts), hi = min(lo + seg, n_utts);
     int32_t s = 0;
@@ -69,17 +69,26 @@ __global__ __launch_bounds__(1024) void k_prepare_scan(const int64_t* __restrict
         s += (int32_t)((F + TILE_FRAMES - 1) / TILE_FRAMES);
         gmax[u] = 0u;
     }
-    part[tid] = s;
+    // inclusive scan inside the wavefront, then over the 16 wavefront totals
+    int32_t inc = s;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t v = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += v;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
     __syncthreads();
+    int32_t before = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        const int32_t v = wave_sum[w];
+        if (w < wave) before += v;
+        total += v;
+    }
     if (tid == 0) {
-        int32_t run = 0;
-        for (int i = 0; i < 1024; ++i) { const int32_t v = part[i]; part[i] = run; run += v; }
-        tile_off[n_utts] = run;
-        hdr->n_tiles = run;
+        tile_off[n_utts] = total;
+        hdr->n_tiles = total;
         hdr->bad_groups = 0;
     }
-    __syncthreads();
-    int32_t run = part[tid];
+    int32_t run = before + inc - s;
     for (int u = lo; u < hi; ++u) {
         tile_off[u] = run;
         const int64_t F = frame_off[u + 1] - frame_off[u];
