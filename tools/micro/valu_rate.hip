@@ -7,7 +7,8 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(float* out, int iters, float s) {
+__global__ __launch_bounds__(256) void k(float* out, int iters, float s, long long* clk) {
+    const long long c0 = clock64(), w0 = wall_clock64();
     float a[8]; f2 p[8];
     for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x * 0.001f + i; p[i] = (f2){a[i], a[i] + 1.0f}; }
     f2 s2 = (f2){s, s};
@@ -29,24 +30,32 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float s) {
     }
     float acc = 0;
     for (int i = 0; i < 8; ++i) acc += a[i] + p[i].x + p[i].y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
     if (acc == 12345.678f) out[0] = acc;
 }
 
 template <int MODE>
 void run(const char* name, float* d, int wavesPerSimd) {
+    static long long* clk = nullptr;
+    if (!clk && hipMalloc(&clk, 16) != hipSuccess) return;
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const int iters = 20000;
     const int blocks = prop.multiProcessorCount * wavesPerSimd;   // 256 threads = 4 waves = 1 per SIMD
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 100, 1.0001f);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 100, 1.0001f, clk);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0001f);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0001f, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double instr_per_simd = (double)iters * 32 * wavesPerSimd;
-    const double clk = prop.clockRate * 1e3;   // Hz
-    printf("%-16s waves/SIMD %d: %.3f ms, %.2f cycles/instr (at %.0f MHz)\n", name, wavesPerSimd, ms,
-           ms * 1e-3 * clk / instr_per_simd, clk / 1e6);
+    const double clkhz = prop.clockRate * 1e3;   // Hz
+    long long h[2] = {0, 0};
+    if (hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost) != hipSuccess) return;
+    // the shader clock counter against the constant 100 MHz counter: the clock the chip really ran at
+    const double mhz = h[1] > 0 ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
+    printf("%-16s waves/SIMD %d: %.3f ms, %.2f cycles/instr at the nominal %.0f MHz, %.2f by the wavefront's own cycle counter (ran at %.0f MHz)\n",
+           name, wavesPerSimd, ms, ms * 1e-3 * clkhz / instr_per_simd, clkhz / 1e6,
+           (double)h[0] / ((double)iters * 32 * wavesPerSimd), mhz);
 }
 
 int main() {

@@ -38,8 +38,9 @@ def soak(seconds: float, seed: int, max_batches: int = 0):
     dev = torch.device("cuda", 0)
     t_end = time.time() + seconds
     n, worst, worst_kw = 0, 0.0, None
+    used, t_say = {}, time.time() + 30.0
     while time.time() < t_end and not (max_batches and n >= max_batches):
-        n_fft = int(rng.choice([2048, 2048, 1024, 512, 400, 256]))
+        n_fft = int(rng.choice([2048, 2048, 2048, 1024, 512, 480, 400, 320, 256]))
         kw = dict(n_fft=n_fft, hop_length=int(rng.integers(n_fft // 8, n_fft + 1)), n_mels=int(rng.choice([20, 40, 64, 80, 128])),
                   n_mfcc=int(rng.choice([13, 20])), sr=int(rng.choice([8000, 16000, 22050])),
                   center=bool(rng.random() < 0.8), pad_mode=str(rng.choice(["constant", "reflect"])))
@@ -76,8 +77,12 @@ def soak(seconds: float, seed: int, max_batches: int = 0):
         assert err <= 1e-2, f"mismatch {err} dB: {kw}, lens {lens[:8]}..."
         if err > worst:
             worst, worst_kw = err, dict(kw, kernel=plan.front_kernel, scale=float(np.abs(ys[0]).max()))
+        used[plan.front_kernel] = used.get(plan.front_kernel, 0) + 1
         plan.close()
         n += 1
+        if time.time() >= t_say:
+            print(f"  {n} batches, worst {worst:.2e} dB, kernels {used}", flush=True)
+            t_say = time.time() + 30.0
     return n, worst, worst_kw
 
 
