@@ -53,9 +53,9 @@ void run(const char* name, float* d, int wavesPerSimd) {
     if (hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost) != hipSuccess) return;
     // the shader clock counter against the constant 100 MHz counter: the clock the chip really ran at
     const double mhz = h[1] > 0 ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
-    printf("%-16s waves/SIMD %d: %.3f ms, %.2f cycles/instr at the nominal %.0f MHz, %.2f by the wavefront's own cycle counter (ran at %.0f MHz)\n",
+    printf("%-16s waves/SIMD %d: %.3f ms, %.2f cycles/instr at the nominal %.0f MHz, one wavefront issues one every %.2f cycles of its own counter (ran at %.0f MHz)\n",
            name, wavesPerSimd, ms, ms * 1e-3 * clkhz / instr_per_simd, clkhz / 1e6,
-           (double)h[0] / ((double)iters * 32 * wavesPerSimd), mhz);
+           (double)h[0] / ((double)iters * 32), mhz);
 }
 
 int main() {
