@@ -57,27 +57,56 @@ FC_HD void cmul(float& xr, float& xi, const float wr, const float wi) {
 // Position in the cfft16 output arrays that holds bin k.
 constexpr int cfft16_pos(int k) { return (k >> 2) + 4 * (k & 3); }
 
+// 4-point DFT in place of (a, wb b, wc c, wd d) where every twiddled input is given as an
+// unscaled vector u with w x = g u: b = g_b ub, c = g_c uc, d = RHO g_b ud (RHO = +-1: all the
+// twiddle pairs of a 16-point transform have |g_d| = |g_b|).  The scales ride on the fused
+// multiply-adds of the butterflies, so a twiddle costs two operations instead of four.
+template <int RHO>
+FC_HD void bfly4_scaled(float& ar, float& ai, float& br, float& bi, float& cr, float& ci, float& dr, float& di,
+                        const float gb, const float gc) {
+    const float s0r = fmaf(gc, cr, ar), s0i = fmaf(gc, ci, ai);      // a + c
+    const float s1r = fmaf(-gc, cr, ar), s1i = fmaf(-gc, ci, ai);    // a - c
+    const float s2r = RHO > 0 ? br + dr : br - dr, s2i = RHO > 0 ? bi + di : bi - di;   // (b + d) / g_b
+    const float s3r = RHO > 0 ? br - dr : br + dr, s3i = RHO > 0 ? bi - di : bi + di;   // (b - d) / g_b
+    ar = fmaf(gb, s2r, s0r);  ai = fmaf(gb, s2i, s0i);               // X0
+    cr = fmaf(-gb, s2r, s0r); ci = fmaf(-gb, s2i, s0i);              // X2
+    br = fmaf(gb, s3i, s1r);  bi = fmaf(-gb, s3r, s1i);              // X1 = (a - c) - i (b - d)
+    dr = fmaf(-gb, s3i, s1r); di = fmaf(gb, s3r, s1i);               // X3 = (a - c) + i (b - d)
+}
+
 // 16-point complex DFT in place.  Input: re[n], im[n] in natural order.  Output: bin k is at
 // index cfft16_pos(k) (base-4 digit reversal).
-// Twiddles and second pass of cfft16, on the outputs of its first pass.
+// Twiddles and second pass of cfft16, on the outputs of its first pass.  The twiddles
+// W16^(n1 k2) (index n1 + 4 k2) are applied in factored form, w x = g u with
+//   |Re w| >= |Im w|:  g = Re w, u = (xr - t xi, xi + t xr), t = Im w / Re w
+//   otherwise:         g = Im w, u = (k xr - xi, xr + k xi), k = Re w / Im w
+// and the scale g goes into the butterfly that follows (bfly4_scaled).
 FC_HD void cfft16_tail(float (&re)[16], float (&im)[16]) {
-    // Twiddles W16^(n1 k2) at index n1 + 4 k2 (n1, k2 in 1..3).
-    cmul(re[5], im[5], W16_1r, W16_1i);     // n1=1,k2=1
-    cmul(re[6], im[6], W16_2r, W16_2i);     // n1=2,k2=1
-    cmul(re[7], im[7], W16_3r, W16_3i);     // n1=3,k2=1
-    cmul(re[9], im[9], W16_2r, W16_2i);     // n1=1,k2=2
-    {                                        // n1=2,k2=2 : W16^4 = -i
-        const float t = re[10]; re[10] = im[10]; im[10] = -t;
+    constexpr float C1 = 0.9238795325112867f;     // cos(pi/8)
+    constexpr float T1 = 0.4142135623730950f;     // tan(pi/8)
+    constexpr float C2 = 0.7071067811865476f;     // cos(pi/4)
+    bfly4(re[0], im[0], re[1], im[1], re[2], im[2], re[3], im[3]);
+    {   // k2 = 1: W^1 = C1 (1, -T1), W^2 = C2 (1, -1), W^3 = -C1 (T1, 1) -> g = (C1, C2, -C1)
+        const float ubr = fmaf(T1, im[5], re[5]), ubi = fmaf(-T1, re[5], im[5]);
+        const float ucr = re[6] + im[6], uci = im[6] - re[6];
+        const float udr = fmaf(-T1, re[7], -im[7]), udi = fmaf(-T1, im[7], re[7]);
+        re[5] = ubr; im[5] = ubi; re[6] = ucr; im[6] = uci; re[7] = udr; im[7] = udi;
+        bfly4_scaled<-1>(re[4], im[4], re[5], im[5], re[6], im[6], re[7], im[7], C1, C2);
     }
-    cmul(re[11], im[11], W16_6r, W16_6i);   // n1=3,k2=2
-    cmul(re[13], im[13], W16_3r, W16_3i);   // n1=1,k2=3
-    cmul(re[14], im[14], W16_6r, W16_6i);   // n1=2,k2=3
-    cmul(re[15], im[15], W16_9r, W16_9i);   // n1=3,k2=3
-    // Pass 2: for each k2, 4-point DFT over n1; X[4 k1 + k2] lands at k1 + 4 k2.
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2)
-        bfly4(re[4 * k2], im[4 * k2], re[4 * k2 + 1], im[4 * k2 + 1], re[4 * k2 + 2],
-              im[4 * k2 + 2], re[4 * k2 + 3], im[4 * k2 + 3]);
+    {   // k2 = 2: W^2 = C2 (1, -1), W^4 = -i, W^6 = -C2 (1, 1) -> g = (C2, 1 with u = (xi, -xr), -C2)
+        const float ubr = re[9] + im[9], ubi = im[9] - re[9];
+        const float ucr = im[10], uci = -re[10];
+        const float udr = re[11] - im[11], udi = im[11] + re[11];
+        re[9] = ubr; im[9] = ubi; re[10] = ucr; im[10] = uci; re[11] = udr; im[11] = udi;
+        bfly4_scaled<-1>(re[8], im[8], re[9], im[9], re[10], im[10], re[11], im[11], C2, 1.0f);
+    }
+    {   // k2 = 3: W^3 = -C1 (T1, 1), W^6 = -C2 (1, 1), W^9 = -C1 (1, -T1) -> g = (-C1, -C2, -C1)
+        const float ubr = fmaf(-T1, re[13], -im[13]), ubi = fmaf(-T1, im[13], re[13]);
+        const float ucr = re[14] - im[14], uci = im[14] + re[14];
+        const float udr = fmaf(T1, im[15], re[15]), udi = fmaf(-T1, re[15], im[15]);
+        re[13] = ubr; im[13] = ubi; re[14] = ucr; im[14] = uci; re[15] = udr; im[15] = udi;
+        bfly4_scaled<1>(re[12], im[12], re[13], im[13], re[14], im[14], re[15], im[15], -C1, -C2);
+    }
 }
 
 FC_HD void cfft16(float (&re)[16], float (&im)[16]) {
@@ -131,10 +160,21 @@ FC_HD void rdft32_split(const float (&zr)[16], const float (&zi)[16], float (&ar
         const float a = zr[cfft16_pos(k)], b = zi[cfft16_pos(k)];
         const float c = zr[cfft16_pos(16 - k)], d = zi[cfft16_pos(16 - k)];
         const float er = a + c, ei = b - d;          // 2 E[k]
-        float tr = b + d, ti = c - a;                // 2 O[k] = -i (Z[k] - conj Z[16-k])
-        cmul(tr, ti, W32r[k], W32i[k]);              // 2 W32^k O[k]
-        ar[k] = er + tr;       ai[k] = ei + ti;      // 2 A[k]
-        ar[16 - k] = er - tr;  ai[16 - k] = ti - ei; // 2 A[16-k] = conj(2E - 2 W^k O)
+        const float tr = b + d, ti = c - a;          // 2 O[k] = -i (Z[k] - conj Z[16-k])
+        // 2 W32^k O[k] = g (ur, ui), the twiddle factored by its larger component (see
+        // cfft16_tail); g rides on the additions
+        float g, ur, ui;
+        if (k < 4) {
+            const float t = W32i[k] / W32r[k];
+            g = W32r[k]; ur = fmaf(-t, ti, tr); ui = fmaf(t, tr, ti);
+        } else if (k == 4) {
+            g = W32r[4]; ur = tr + ti; ui = ti - tr;
+        } else {
+            const float q = W32r[k] / W32i[k];
+            g = W32i[k]; ur = fmaf(q, tr, -ti); ui = fmaf(q, ti, tr);
+        }
+        ar[k] = fmaf(g, ur, er);        ai[k] = fmaf(g, ui, ei);        // 2 A[k]
+        ar[16 - k] = fmaf(-g, ur, er);  ai[16 - k] = fmaf(g, ui, -ei);  // 2 A[16-k] = conj(2E - 2 W^k O)
     }
 }
 
