@@ -10,6 +10,7 @@
 //   k_db_dct                          10 log10, top_db clamp against the utterance maximum,
 //                                     DCT on v_mfma_f32_16x16x4_f32, lifter, (F, n_mfcc) store
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cmath>
 #include <cstdio>
@@ -152,6 +153,39 @@ struct DbDctArgs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// power_to_db in the log2 domain.  10 log10(max(amin, S)) - ref_db, clamped at the utterance's
+// maximum - top_db, equals DB_PER_LOG2 * (log2(max(S, amin, floor)) - ref_l): the clamp becomes a
+// floor on the power itself (log2 is monotonic), the factor is applied to the DCT's output and
+// ref_l = ref_db / DB_PER_LOG2 is subtracted only when ref is not 1 -- per mel value one
+// three-way maximum and one v_log_f32 remain.  amin below the smallest normal number takes the
+// library logarithm instead (v_log_f32 does not take subnormal inputs).
+constexpr float DB_PER_LOG2 = 3.010299956639812f;   // 10 log10(2)
+struct DbScale {
+    float floor_pw;   // power below which a value is clamped (0: no clamp)
+    float ref_l;      // ref_db / DB_PER_LOG2
+};
+__device__ __forceinline__ DbScale db_scale(const DbDctArgs& a, float gmax_pw) {
+    DbScale d;
+    d.ref_l = a.ref_db * (1.0f / DB_PER_LOG2);
+    d.floor_pw = 0.0f;
+    if (a.top_db >= 0.0f) {
+        const float lm = log2f(fmaxf(a.amin, gmax_pw)) - a.top_db * (1.0f / DB_PER_LOG2);
+        d.floor_pw = exp2f(lm);
+    }
+    return d;
+}
+// MODE 0: amin normal, ref = 1 (the reference's case); 1: amin normal, other ref; 2: library log2
+template <int MODE>
+__device__ __forceinline__ float db_log2(const DbDctArgs& a, const DbScale& d, float v) {
+    const float x = fmaxf(fmaxf(v, a.amin), d.floor_pw);
+    if (MODE == 0) return __builtin_amdgcn_logf(x);
+    if (MODE == 1) return __builtin_amdgcn_logf(x) - d.ref_l;
+    return log2f(x) - d.ref_l;
+}
+__device__ __forceinline__ int db_mode(const DbDctArgs& a) {
+    return a.amin >= 1.0e-37f ? (a.ref_db == 0.0f ? 0 : 1) : 2;
+}
+
 __global__ __launch_bounds__(256) void k_db_dct(const DbDctArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -163,12 +197,8 @@ __global__ __launch_bounds__(256) void k_db_dct(const DbDctArgs a) {
     const int64_t row = ti.row0 + min(f, nvalid - 1);
     const float* mrow = a.mel + row * a.n_mels;
 
-    float thr = -INFINITY;
-    if (a.top_db >= 0.0f) {
-        const float gm = __uint_as_float(a.gmax[ti.grp]);
-        const float maxdb = 10.0f * log10f(fmaxf(a.amin, gm)) - a.ref_db;
-        thr = maxdb - a.top_db;
-    }
+    const DbScale ds = db_scale(a, a.top_db >= 0.0f ? __uint_as_float(a.gmax[ti.grp]) : 0.0f);
+    const int mode = db_mode(a);
 
     const int steps_total = a.n_mels_pad / 4;
     for (int rt0 = 0; rt0 < a.n_rt; rt0 += 4) {
@@ -189,10 +219,8 @@ __global__ __launch_bounds__(256) void k_db_dct(const DbDctArgs a) {
                     for (int i = 0; i < 4; ++i) v[i] = (k + i < a.n_mels) ? mrow[k + i] : 0.0f;
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float db = 10.0f * log10f(fmaxf(a.amin, v[i])) - a.ref_db;
-                    L[4 * j + i] = fmaxf(db, thr);
-                }
+                for (int i = 0; i < 4; ++i)
+                    L[4 * j + i] = mode == 0 ? db_log2<0>(a, ds, v[i]) : mode == 1 ? db_log2<1>(a, ds, v[i]) : db_log2<2>(a, ds, v[i]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -211,7 +239,7 @@ __global__ __launch_bounds__(256) void k_db_dct(const DbDctArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int cidx = (rt0 + r) * 16 + 4 * kq + i;
-                    if (cidx < a.n_mfcc) orow[cidx] = acc[r][i] * a.lifter[cidx];
+                    if (cidx < a.n_mfcc) orow[cidx] = acc[r][i] * (DB_PER_LOG2 * a.lifter[cidx]);
                 }
             }
         }
@@ -234,7 +262,8 @@ __global__ __launch_bounds__(256) void k_db_dct_small(const DbDctArgs a) {
     for (int s = 0; s < 4 * NQ; ++s) frag[s] = a.dct_frag[s * 64 + lane];
     float lift[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lift[i] = (4 * kq + i < a.n_mfcc) ? a.lifter[4 * kq + i] : 0.0f;
+    for (int i = 0; i < 4; ++i) lift[i] = (4 * kq + i < a.n_mfcc) ? DB_PER_LOG2 * a.lifter[4 * kq + i] : 0.0f;
+    const int mode = db_mode(a);
     // mel index of this lane's last quad; past the row's end its DCT weights are zero and the
     // load is redirected to the row's start
     const int last_k = 16 * (NQ - 1) + 4 * kq;
@@ -257,21 +286,21 @@ __global__ __launch_bounds__(256) void k_db_dct_small(const DbDctArgs a) {
     for (; tile < n_tiles; tile += n_waves) {
         const bool more = tile + n_waves < n_tiles;
         if (more) load_tile(tile + n_waves, ti_n, tn);
-        float thr = -INFINITY;
-        if (a.top_db >= 0.0f) {
-            const float gm = __uint_as_float(a.gmax[ti.grp]);
-            thr = 10.0f * log10f(fmaxf(a.amin, gm)) - a.ref_db - a.top_db;
-        }
+        const DbScale ds = db_scale(a, a.top_db >= 0.0f ? __uint_as_float(a.gmax[ti.grp]) : 0.0f);
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto contract = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const float v[4] = {t[j].x, t[j].y, t[j].z, t[j].w};
+            for (int j = 0; j < NQ; ++j) {
+                const float v[4] = {t[j].x, t[j].y, t[j].z, t[j].w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float db = fmaxf(10.0f * log10f(fmaxf(a.amin, v[i])) - a.ref_db, thr);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[4 * j + i], db, acc, 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[4 * j + i], db_log2<MODE>(a, ds, v[i]), acc, 0, 0, 0);
             }
-        }
+        };
+        if (mode == 0) contract(std::integral_constant<int, 0>{});
+        else if (mode == 1) contract(std::integral_constant<int, 1>{});
+        else contract(std::integral_constant<int, 2>{});
         const int nvalid = min(TILE_FRAMES, ti.F - ti.f0);
         if (f < nvalid) {
             float* orow = a.out + (ti.row0 + f) * a.n_mfcc;
