@@ -866,7 +866,10 @@ int mfcc_batch_layout(const mfcc_config* cfg, const int64_t* h_sample_offsets, i
     for (int u = 0; u < n_utts; ++u) {
         const int64_t T = h_sample_offsets[u + 1] - h_sample_offsets[u];
         if (T < 0) return fail(MFCC_E_INVALID, "sample offsets must be non-decreasing");
-        if (T > 0x7fffffffLL) return fail(MFCC_E_UNSUPPORTED, "utterances of 2^31 samples or more");
+        // the kernels index an utterance's samples with 32-bit integers, up to one transform length
+        // past its end
+        if (T > 0x7fffffffLL - 4LL * r.c.n_fft)
+            return fail(MFCC_E_UNSUPPORTED, "utterances of 2^31 - 4 n_fft samples or more");
         const int64_t F = mfcc_host::num_frames(r, T);
         if (F < 0)
             return fail(MFCC_E_INVALID, "n_fft is too large for uncentered analysis of utterance " +

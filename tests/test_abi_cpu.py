@@ -105,6 +105,14 @@ def test_num_frames_and_batch_layout():
     rc = lib.mfcc_batch_layout(C.byref(c2), so.ctypes.data_as(C.POINTER(C.c_int64)), len(lens),
                                fo.ctypes.data_as(C.POINTER(C.c_int64)))
     assert rc == _lib.MFCC_E_INVALID and "uncentered" in _lib.last_error()
+    # an utterance is indexed with 32-bit integers: 2^31 samples (37 h at 16 kHz) is refused, and
+    # so is one that comes within a few transform lengths of it
+    for T, ok in ((2 ** 31 - 1 - 4 * 2048, True), (2 ** 31 - 4 * 2048, False), (2 ** 31, False)):
+        so1 = np.array([0, T], dtype=np.int64)
+        fo1 = np.zeros(2, dtype=np.int64)
+        rc = lib.mfcc_batch_layout(C.byref(c), so1.ctypes.data_as(C.POINTER(C.c_int64)), 1,
+                                   fo1.ctypes.data_as(C.POINTER(C.c_int64)))
+        assert (rc == 0) == ok and (ok or rc == _lib.MFCC_E_UNSUPPORTED)
 
 
 @pytest.mark.parametrize("field,value", [("n_fft", 0), ("n_fft", 401), ("hop_length", 0), ("win_length", 4096),
