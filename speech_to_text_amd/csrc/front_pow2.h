@@ -25,6 +25,13 @@
 
 #include "front_2048.h"
 
+// 1: at eight columns per frame (n_fft = 1024) the window sits in LDS as well (measured: 1.74 ms
+// per 10 h with window and step-1 twiddles in registers and 11 spilled registers, 1.69 with the
+// twiddles in LDS, 1.655 with both there and no spills)
+#ifndef MFCC_P2_WIN_LDS
+#define MFCC_P2_WIN_LDS 1
+#endif
+
 namespace kp2 {
 
 constexpr int SPEC_STRIDE = 136;   // floats between the frames' special-column scratch areas
@@ -45,6 +52,10 @@ struct Geo {
     static constexpr int T = 16 / R;           // frames per pass
     static constexpr int ROWS = 2 * R;         // samples per lane and frame
     static constexpr int NB = N / 2 + 1;
+    // step-1 twiddles: registers up to four columns, LDS beyond (at eight columns the 14
+    // registers they would take are what the kernel spills)
+    static constexpr int TW_LDS_FLOATS = R >= 8 ? (R - 1) * 64 * 2 + MFCC_P2_WIN_LDS * N : 0;
+    static constexpr bool WIN_LDS = R >= 8 && MFCC_P2_WIN_LDS;
     static constexpr int SCR_OFF = LOG2N == 9 ? 1504 : LOG2N == 10 ? 1776 : 1296;
     static constexpr int REGION = (SCR_OFF + T * SPEC_STRIDE + 63) / 64 * 64 < k2048::XCH_FLOATS
                                       ? k2048::XCH_FLOATS
@@ -62,8 +73,8 @@ struct Geo {
 static_assert(Geo<9>::REGION == 2048 && Geo<10>::REGION == 2048, "exchange-sized regions expected");
 
 // mel_quads: weight quads of all rounds together; fpr: filters per round
-constexpr size_t lds_bytes(int region, int waves, int fpr, int mel_quads, int mel_rounds) {
-    return sizeof(float) * ((size_t)waves * region + k2048::W64_FLOATS + 4 * (size_t)mel_quads * fpr +
+constexpr size_t lds_bytes(int region, int waves, int fpr, int mel_quads, int mel_rounds, int tw_floats = 0) {
+    return sizeof(float) * ((size_t)waves * region + k2048::W64_FLOATS + tw_floats + 4 * (size_t)mel_quads * fpr +
                             2 * 64 * (size_t)mel_rounds + 4 /* unit counter */);
 }
 
@@ -126,6 +137,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
     float* tab = lds + WAVES * REGION;
     float2* w64_l = reinterpret_cast<float2*>(tab);
     tab += W64_FLOATS;
+    constexpr bool TW_LDS = G::TW_LDS_FLOATS > 0;
+    float2* tw_l = reinterpret_cast<float2*>(tab);
+    tab += G::TW_LDS_FLOATS;
     float4* melw_l = reinterpret_cast<float4*>(tab);
     constexpr int FPR = 64 / T;                     // filters per mel round
     uint2* pairs_l = reinterpret_cast<uint2*>(melw_l + a.mel_quads * FPR);
@@ -138,6 +152,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
         const int m = tid & 15;
         w64_l[(tid >> 4) * W64_STRIDE + (m ? m - 1 : 15)] = m ? a.w64[tid] : make_float2(0.0f, 0.0f);
     }
+    float4* win_l = reinterpret_cast<float4*>(tw_l + (R - 1) * 64);   // quads (j, j+1, j+2, j+3) of row group j / 4
+    if (TW_LDS) {
+        for (int i = tid; i < (R - 1) * 64; i += THREADS) tw_l[i] = a.tw1[i];
+        if (G::WIN_LDS) {
+            for (int i = tid; i < N / 4; i += THREADS) {
+                const int g = i >> 6, l = i & 63;
+                win_l[i] = make_float4(a.window[l + 64 * (4 * g)], a.window[l + 64 * (4 * g + 1)],
+                                       a.window[l + 64 * (4 * g + 2)], a.window[l + 64 * (4 * g + 3)]);
+            }
+        }
+    }
     for (int i = tid; i < a.mel_quads * FPR; i += THREADS) melw_l[i] = a.melw[i];
     for (int i = tid; i < a.mel_rounds * 64; i += THREADS) pairs_l[i] = a.mel_pairs[i];
     if (tid == 0) *run_ctr = 0;
@@ -148,10 +173,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
     const int k2 = slot & (R - 1), tf = slot / R;   // step 2: column and frame of this lane
     float win[ROWS];
 #pragma unroll
-    for (int j = 0; j < ROWS; ++j) win[j] = a.window[lane + 64 * j];
+    for (int j = 0; j < ROWS; ++j) win[j] = G::WIN_LDS ? 0.0f : a.window[lane + 64 * j];
     float2 tw[R];
 #pragma unroll
-    for (int k = 1; k < R; ++k) tw[k] = a.tw1[(k - 1) * 64 + lane];
+    for (int k = 1; k < R; ++k) tw[k] = TW_LDS ? make_float2(0.0f, 0.0f) : a.tw1[(k - 1) * 64 + lane];
     const float2 tw128 = a.tw128[lane];
 
     // Quad DFT-4 signs (see front_2048.h): lanes 1..3 of a quad end up with negated outputs, which
@@ -254,10 +279,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
                 for (int j = 0; j < ROWS; ++j) rt[j] = X[lane + 64 * j];
             }
         }
+        if (G::WIN_LDS) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
+            for (int g = 0; g < ROWS / 4; ++g) {
+                const float4 w4 = win_l[64 * g + lane];
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) r[t * ROWS + j] *= win[j];
+                for (int t = 0; t < T; ++t) {
+                    r[t * ROWS + 4 * g] *= w4.x; r[t * ROWS + 4 * g + 1] *= w4.y;
+                    r[t * ROWS + 4 * g + 2] *= w4.z; r[t * ROWS + 4 * g + 3] *= w4.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int j = 0; j < ROWS; ++j) r[t * ROWS + j] *= win[j];
+            }
         }
 
         // ---- step 1: real DFT over n2, twiddle, exchange -------------------------------------------
@@ -270,7 +307,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
             X[2 * COL_STRIDE * s0 + y1[s0 & 3]] = ai[0];   // y[64 + n1] = sum over odd n2
 #pragma unroll
             for (int k = 1; k < R; ++k) {
-                fc::cmul(ar[k], ai[k], tw[k].x, tw[k].y);
+                const float2 twk = TW_LDS ? tw_l[(k - 1) * 64 + lane] : tw[k];
+                fc::cmul(ar[k], ai[k], twk.x, twk.y);
                 X2[(s0 + k) * COL_STRIDE + xw[(s0 + k) & 3]] = make_float2(ar[k], ai[k]);
             }
         }

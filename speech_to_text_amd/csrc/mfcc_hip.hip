@@ -729,12 +729,12 @@ bool build_pow2_tables(mfcc_plan* p, const std::vector<float>& basis, std::vecto
         return false;
     p->p2_waves = 0;
     for (int w : {16, 8})
-        if (kp2::lds_bytes(G::REGION, w, 64 / G::T, p->p2_quads, p->p2_rounds) <= (size_t)k2048::LDS_LIMIT) {
+        if (kp2::lds_bytes(G::REGION, w, 64 / G::T, p->p2_quads, p->p2_rounds, G::TW_LDS_FLOATS) <= (size_t)k2048::LDS_LIMIT) {
             p->p2_waves = w;
             break;
         }
     if (!p->p2_waves) return false;
-    p->p2_lds_bytes = kp2::lds_bytes(G::REGION, p->p2_waves, 64 / G::T, p->p2_quads, p->p2_rounds);
+    p->p2_lds_bytes = kp2::lds_bytes(G::REGION, p->p2_waves, 64 / G::T, p->p2_quads, p->p2_rounds, G::TW_LDS_FLOATS);
     return true;
 }
 
