@@ -26,6 +26,10 @@
 
 #include "front_pow2.h"
 
+#ifndef MFCC_16A_WIN_LDS
+#define MFCC_16A_WIN_LDS (1 << 30)
+#endif
+
 namespace k16a {
 constexpr int T = 4;                    // frames per wavefront pass
 constexpr int COL = 36;                 // floats per exchange column: 16 complex + 4 floats of padding
@@ -41,8 +45,15 @@ struct Geo {
     static constexpr int REGION_MIN = T * NC * COL > T * P_STRIDE ? T * NC * COL : T * P_STRIDE;
     static constexpr int REGION = REGION_MIN > k2048::XCH_FLOATS ? (REGION_MIN + 63) / 64 * 64 : k2048::XCH_FLOATS;
     static constexpr int p_base(int t) { return P_STRIDE * t; }
+    // The window: A registers per lane, or (bit A of MFCC_16A_WIN_LDS) a table in LDS as [b][a],
+    // rows WIN_ROW floats apart -- a multiple of 4 whose quarter is odd, so that the 16-byte reads
+    // of the 16 residues b fall into 16 different bank groups.  Default: LDS at A = 30, where the
+    // 30 registers are what the kernel spills.
+    static constexpr bool WIN_LDS = (MFCC_16A_WIN_LDS >> A) & 1;
+    static constexpr int WIN_ROW = ((A + 3) / 4) % 2 ? (A + 3) / 4 * 4 : (A + 3) / 4 * 4 + 4;
+    static constexpr int WIN_FLOATS = WIN_LDS ? 16 * WIN_ROW : 0;
     static constexpr size_t lds_bytes(int waves, int mel_quads, int mel_rounds) {
-        return sizeof(float) * ((size_t)waves * REGION + TW_FLOATS + 4 * (size_t)mel_quads * (64 / T) +
+        return sizeof(float) * ((size_t)waves * REGION + TW_FLOATS + WIN_FLOATS + 4 * (size_t)mel_quads * (64 / T) +
                                 2 * 64 * (size_t)mel_rounds + 4 /* unit counter */);
     }
 };
@@ -73,12 +84,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_16a(const Pow2Args a) {
     float* tab = lds + WAVES * REGION;
     float2* tw_l = reinterpret_cast<float2*>(tab);
     tab += TW_FLOATS;
+    float* win_l = tab;
+    tab += G::WIN_FLOATS;
     float4* melw_l = reinterpret_cast<float4*>(tab);
     uint2* pairs_l = reinterpret_cast<uint2*>(melw_l + a.mel_quads * FPR);
     int* run_ctr = reinterpret_cast<int*>(pairs_l + a.mel_rounds * 64);
 
     for (int i = tid; i < WAVES * REGION; i += THREADS) lds[i] = 0.0f;
     for (int i = tid; i < TW_FLOATS / 2; i += THREADS) tw_l[i] = a.tw1[i];
+    for (int i = tid; i < G::WIN_FLOATS; i += THREADS) {
+        const int wb = i / G::WIN_ROW, wa = i - wb * G::WIN_ROW;
+        win_l[i] = wa < NA ? a.window[16 * wa + wb] : 0.0f;
+    }
     for (int i = tid; i < a.mel_quads * FPR; i += THREADS) melw_l[i] = a.melw[i];
     for (int i = tid; i < a.mel_rounds * 64; i += THREADS) pairs_l[i] = a.mel_pairs[i];
     if (tid == 0) *run_ctr = 0;
@@ -90,7 +107,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_16a(const Pow2Args a) {
     const bool active2 = lane < T * NC;
     float win[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) win[i] = a.window[16 * i + b];
+    for (int i = 0; i < NA; ++i) win[i] = G::WIN_LDS ? 0.0f : a.window[16 * i + b];
+    const float4* win_q = reinterpret_cast<const float4*>(win_l + b * G::WIN_ROW);
     const int xw = (tf * NC * COL) / 2 + b;         // complex index of Z[b][0] of frame tf
     const float* xr = X + col * COL;
     const int pb = G::p_base(t2);
@@ -163,8 +181,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_16a(const Pow2Args a) {
                 }
             }
         }
+        if (G::WIN_LDS) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) x[i] *= win[i];
+            for (int j = 0; j < (NA + 3) / 4; ++j) {
+                const float4 w = win_q[j];
+                x[4 * j] *= w.x;
+                if (4 * j + 1 < NA) x[4 * j + 1] *= w.y;
+                if (4 * j + 2 < NA) x[4 * j + 2] *= w.z;
+                if (4 * j + 3 < NA) x[4 * j + 3] *= w.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) x[i] *= win[i];
+        }
 
         // ---- step 1: real DFT-25 over a, twiddle, exchange -----------------------------------------
         {
