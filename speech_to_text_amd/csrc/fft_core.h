@@ -7,7 +7,7 @@
 //   rdft32 : 32-point DFT of a REAL sequence (bins 0..16) from one cfft16 of the packed
 //            sequence z[m] = r[2m] + i r[2m+1] plus the conjugate-symmetric split.
 //   rdft_cols<R> : the same for 2R = 4, 8, 16 points;  rdft25 : 25-point real DFT (5 x 5);
-//   rdft_even<A> : 20- and 30-point real DFTs, folded direct sums.
+//   rdft_even<A> : 20-, 30- and 40-point real DFTs, folded direct sums.
 //
 // Forward transform convention, as numpy.fft: X[k] = sum_n x[n] exp(-2 pi i n k / N).
 #pragma once
@@ -332,11 +332,32 @@ constexpr float S30[30] = {
     -0.9945218953682733f, -0.9945218953682734f, -0.9510565162951536f, -0.8660254037844386f,
     -0.743144825477394f, -0.5877852522924734f, -0.40673664307580015f, -0.20791169081775898f};
 
+// cos, sin of 2 pi j / 40
+constexpr float C40[40] = {
+    1.0f, 0.9876883405951378f, 0.9510565162951535f, 0.8910065241883679f, 0.8090169943749475f,
+    0.7071067811865476f, 0.5877852522924731f, 0.4539904997395468f, 0.30901699437494745f, 0.15643446504023092f,
+    0.0f, -0.1564344650402306f, -0.30901699437494734f, -0.4539904997395467f, -0.587785252292473f,
+    -0.7071067811865475f, -0.8090169943749473f, -0.8910065241883678f, -0.9510565162951535f, -0.9876883405951377f,
+    -1.0f, -0.9876883405951378f, -0.9510565162951538f, -0.8910065241883679f, -0.8090169943749476f,
+    -0.7071067811865477f, -0.5877852522924732f, -0.4539904997395469f, -0.30901699437494756f, -0.15643446504023104f,
+    0.0f, 0.15643446504023067f, 0.30901699437494723f, 0.45399049973954664f, 0.5877852522924729f,
+    0.7071067811865474f, 0.8090169943749473f, 0.8910065241883678f, 0.9510565162951535f, 0.9876883405951377f};
+constexpr float S40[40] = {
+    0.0f, 0.15643446504023087f, 0.3090169943749474f, 0.45399049973954675f, 0.5877852522924731f,
+    0.7071067811865475f, 0.8090169943749475f, 0.8910065241883678f, 0.9510565162951535f, 0.9876883405951378f,
+    1.0f, 0.9876883405951378f, 0.9510565162951536f, 0.8910065241883679f, 0.8090169943749475f,
+    0.7071067811865476f, 0.5877852522924732f, 0.45399049973954686f, 0.3090169943749475f, 0.15643446504023098f,
+    0.0f, -0.15643446504023073f, -0.3090169943749469f, -0.4539904997395467f, -0.587785252292473f,
+    -0.7071067811865475f, -0.8090169943749473f, -0.8910065241883678f, -0.9510565162951535f, -0.9876883405951377f,
+    -1.0f, -0.9876883405951378f, -0.9510565162951536f, -0.891006524188368f, -0.8090169943749476f,
+    -0.7071067811865477f, -0.5877852522924734f, -0.45399049973954697f, -0.3090169943749476f, -0.15643446504023112f};
+
 template <int A> struct TrigTable;
 template <> struct TrigTable<20> { static constexpr const float* c() { return C20; } static constexpr const float* s() { return S20; } };
 template <> struct TrigTable<30> { static constexpr const float* c() { return C30; } static constexpr const float* s() { return S30; } };
+template <> struct TrigTable<40> { static constexpr const float* c() { return C40; } static constexpr const float* s() { return S40; } };
 
-// Real A-point DFT for even A (20, 30), bins 0 .. A/2: Y[c] = sum_a x[a] exp(-2 pi i a c / A), by
+// Real A-point DFT for even A (20, 30, 40), bins 0 .. A/2: Y[c] = sum_a x[a] exp(-2 pi i a c / A), by
 // the direct sum folded twice.  With H = A/2, p[a] = x[a] + x[A-a] and q[a] = x[a] - x[A-a]
 // (a = 1 .. H-1),
 //     Re Y[c] = x[0] + (-1)^c x[H] + sum_a p[a] cos(2 pi a c / A),   Im Y[c] = -sum_a q[a] sin(2 pi a c / A);

@@ -1,6 +1,7 @@
-// Front end for n_fft = 16 A with A = 20, 25, 30 (n_fft = 320, 400, 480: the 20, 25 and 30 ms
-// windows of 16 kHz speech front ends taken as the transform length, e.g. n_fft = 400, hop 160,
-// 80 mels) on gfx950: one wavefront per four consecutive frames, no barriers in the frame loop.
+// Front end for n_fft = 16 A with A = 20, 25, 30, 40 (n_fft = 320, 400, 480, 640: the 20, 25, 30
+// and 40 ms windows of 16 kHz speech front ends taken as the transform length, e.g. n_fft = 400,
+// hop 160, 80 mels) on gfx950: one wavefront per four consecutive frames, no barriers in the
+// frame loop.
 //
 //   pad / frame / window -> N-point real DFT (A x 16) -> |X|^power -> sparse mel filterbank
 //
@@ -15,7 +16,8 @@
 //  twiddle Z[b][c] = Y[b][c] W_N^(b c)
 //  exchange through LDS: column (t, c) = 16 complex, columns 36 floats apart (conflict-free
 //          16-byte reads)
-//  step 2  lane t NC + c (NC = A/2 + 1 columns per frame) reads its column and does the 16-point
+//  step 2  lane t NC + c (NC = A/2 + 1 columns per frame; beyond 64 columns, at A = 40, a lane
+//          takes a second column, lane + 64) reads its column and does the 16-point
 //          DFT over b in registers -> X[c + A d]; d >= 8 are the mirror images N - k of the
 //          columns c > A/2 (for even A the middle column c = A/2 mirrors onto itself)
 //  mel     as in front_pow2.h: lane = (frame, filter) pair, 16 filters per round
@@ -27,7 +29,7 @@
 #include "front_pow2.h"
 
 #ifndef MFCC_16A_WIN_LDS
-#define MFCC_16A_WIN_LDS (1 << 30)
+#define MFCC_16A_WIN_LDS ((1ULL << 30) | (1ULL << 40))
 #endif
 
 namespace k16a {
@@ -35,9 +37,10 @@ constexpr int T = 4;                    // frames per wavefront pass
 constexpr int COL = 36;                 // floats per exchange column: 16 complex + 4 floats of padding
 template <int A>
 struct Geo {
-    static_assert(A == 20 || A == 25 || A == 30, "supported: n_fft = 320, 400, 480");
+    static_assert(A == 20 || A == 25 || A == 30 || A == 40, "supported: n_fft = 320, 400, 480, 640");
     static constexpr int N = 16 * A, NB = N / 2 + 1, NA = A, NC = A / 2 + 1;   // NC columns per frame
-    static_assert(T * NC <= 64, "one lane per column");
+    static constexpr int ROUNDS = (T * NC + 63) / 64;                          // step-2 columns per lane
+    static_assert(ROUNDS <= 2, "at most two columns per lane");
     // frame t's power spectrum starts at float P_STRIDE t: the bases are 16 floats apart modulo
     // 64, so the T NC lanes of a store (NC <= 16 consecutive bins per frame) hit different banks
     static constexpr int P_STRIDE = (NB + 8 + 47) / 64 * 64 + 16;
@@ -48,8 +51,8 @@ struct Geo {
     // The window: A registers per lane, or (bit A of MFCC_16A_WIN_LDS) a table in LDS as [b][a],
     // rows WIN_ROW floats apart -- a multiple of 4 whose quarter is odd, so that the 16-byte reads
     // of the 16 residues b fall into 16 different bank groups.  Default: LDS at A = 30, where the
-    // 30 registers are what the kernel spills.
-    static constexpr bool WIN_LDS = (MFCC_16A_WIN_LDS >> A) & 1;
+    // 30 registers are what the kernel spills, and at A = 40.
+    static constexpr bool WIN_LDS = ((unsigned long long)(MFCC_16A_WIN_LDS) >> A) & 1;
     static constexpr int WIN_ROW = ((A + 3) / 4) % 2 ? (A + 3) / 4 * 4 : (A + 3) / 4 * 4 + 4;
     static constexpr int WIN_FLOATS = WIN_LDS ? 16 * WIN_ROW : 0;
     static constexpr size_t lds_bytes(int waves, int mel_quads, int mel_rounds) {
@@ -102,16 +105,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_16a(const Pow2Args a) {
     __syncthreads();
 
     const int b = lane & 15, tf = lane >> 4;        // step 1: residue and frame of this lane
-    const int col = min(lane, T * NC - 1);          // step 2: column t2 * NC + c2 (lanes >= T NC idle)
-    const int t2 = col / NC, c2 = col - t2 * NC;
-    const bool active2 = lane < T * NC;
+    // step 2: round r gives this lane column lane + 64 r = t2 NC + c2 (lanes past T NC idle)
+    constexpr int ROUNDS = G::ROUNDS;
+    int c2[ROUNDS], pb[ROUNDS];
+    bool active2[ROUNDS];
+    const float* xr[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int col = min(lane + 64 * r, T * NC - 1);
+        const int t2 = col / NC;
+        c2[r] = col - t2 * NC;
+        pb[r] = G::p_base(t2);
+        active2[r] = lane + 64 * r < T * NC;
+        xr[r] = X + col * COL;
+    }
     float win[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) win[i] = G::WIN_LDS ? 0.0f : a.window[16 * i + b];
     const float4* win_q = reinterpret_cast<const float4*>(win_l + b * G::WIN_ROW);
     const int xw = (tf * NC * COL) / 2 + b;         // complex index of Z[b][0] of frame tf
-    const float* xr = X + col * COL;
-    const int pb = G::p_base(t2);
 
     float runmax = 0.0f;
     int cur_grp = -1;
@@ -211,26 +223,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_16a(const Pow2Args a) {
         }
 
         // ---- step 2: DFT-16 over b ---------------------------------------------------------------
-        float dr[16], di[16];
+        // (every column is read before the first power spectrum is stored: the two share the region)
+        float dr[ROUNDS][16], di[ROUNDS][16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(xr + 4 * j);
-            dr[2 * j] = v.x; di[2 * j] = v.y; dr[2 * j + 1] = v.z; di[2 * j + 1] = v.w;
+        for (int r = 0; r < ROUNDS; ++r) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(xr[r] + 4 * j);
+                dr[r][2 * j] = v.x; di[r][2 * j] = v.y; dr[r][2 * j + 1] = v.z; di[r][2 * j + 1] = v.w;
+            }
         }
-        fc::cfft16(dr, di);
 
         // ---- power spectra -> LDS (natural bin order per frame) --------------------------------------
         // bin c2 + A d for d < 8; d >= 8 is the mirror image A (16 - d) - c2 (for c2 = 0 only
         // d = 8, bin N/2: the others repeat bins A d; for even A the column c2 = A/2 mirrors onto
         // its own bins, so its d >= 8 are skipped)
-        if (active2) {
-            const bool mirrors = c2 != 0 && (A % 2 != 0 || c2 != A / 2);
 #pragma unroll
-            for (int d = 0; d < 16; ++d) {
-                const float re = dr[fc::cfft16_pos(d)], im = di[fc::cfft16_pos(d)];
-                const float pw = apply_power<PW>(re * re + im * im, a.pw_mode, a.half_power);
-                if (d < 8) X[pb + c2 + A * d] = pw;
-                else if ((d == 8 && c2 == 0) || mirrors) X[pb + A * (16 - d) - c2] = pw;
+        for (int r = 0; r < ROUNDS; ++r) {
+            fc::cfft16(dr[r], di[r]);
+            if (active2[r]) {
+                const int c = c2[r];
+                const bool mirrors = c != 0 && (A % 2 != 0 || c != A / 2);
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const float re = dr[r][fc::cfft16_pos(d)], im = di[r][fc::cfft16_pos(d)];
+                    const float pw = apply_power<PW>(re * re + im * im, a.pw_mode, a.half_power);
+                    if (d < 8) X[pb[r] + c + A * d] = pw;
+                    else if ((d == 8 && c == 0) || mirrors) X[pb[r] + A * (16 - d) - c] = pw;
+                }
             }
         }
 

@@ -84,7 +84,9 @@ def test_reference_default_one_utterance(S):
     dict(n_fft=320, hop_length=160, n_mels=40, sr=16000),          # 20 x 16 in-register kernel
     dict(n_fft=480, hop_length=160, n_mels=80, sr=16000),          # 30 x 16 in-register kernel
     dict(n_fft=480, hop_length=240, n_mels=128, sr=22050, pad_mode="reflect"),
-    dict(n_fft=640, hop_length=160, n_mels=40, sr=16000),          # dense-DFT kernel
+    dict(n_fft=640, hop_length=160, n_mels=40, sr=16000),          # 40 x 16 in-register kernel
+    dict(n_fft=640, hop_length=320, n_mels=128, sr=22050, pad_mode="reflect"),
+    dict(n_fft=600, hop_length=150, n_mels=40, sr=16000),          # dense-DFT kernel
     dict(n_fft=512, hop_length=160, n_mels=10, sr=16000),          # wide filters on the 512-point kernel
     dict(n_fft=1024, hop_length=256, n_mels=256, sr=44100),        # 16 mel rounds of 32 filters
     dict(n_fft=400, hop_length=160, n_mels=1, sr=16000),
@@ -125,7 +127,7 @@ def test_mfcc_parity(S, kw):
     np.testing.assert_allclose(got, want, rtol=0, atol=DB_TOL)
 
 
-@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160), (512, 128), (1024, 256), (256, 64), (480, 160), (320, 80)])
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160), (512, 128), (1024, 256), (256, 64), (480, 160), (320, 80), (640, 160)])
 def test_spectrogram_parity(S, n_fft, hop):
     y = speech_like(30000, seed=4)
     want = np.abs(R.stft(y, n_fft=n_fft, hop_length=hop)) ** 2

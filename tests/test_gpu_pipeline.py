@@ -163,7 +163,8 @@ def test_int16_pcm_ingest_is_bit_identical(gpu, kw):
     (dict(n_fft=400, hop_length=160, n_mels=80, sr=16000), "fft400"),
     (dict(n_fft=320, hop_length=160, n_mels=40, sr=16000), "fft320"),
     (dict(n_fft=480, hop_length=160, n_mels=80, sr=16000), "fft480"),
-    (dict(n_fft=640, hop_length=160, n_mels=80, sr=16000), "dense_dft"),
+    (dict(n_fft=640, hop_length=160, n_mels=80, sr=16000), "fft640"),
+    (dict(n_fft=600, hop_length=150, n_mels=80, sr=16000), "dense_dft"),
 ])
 def test_front_kernel_selection(gpu, kw, name):
     import speech_to_text_amd as S
@@ -188,6 +189,9 @@ def test_front_kernel_selection(gpu, kw, name):
     dict(n_fft=480, hop_length=480, n_mels=23, n_mfcc=13, sr=16000, center=False, power=1.0),
     dict(n_fft=320, hop_length=160, n_mels=40, n_mfcc=13, sr=16000),
     dict(n_fft=320, hop_length=77, n_mels=80, n_mfcc=20, sr=16000, pad_mode="reflect"),
+    dict(n_fft=640, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
+    dict(n_fft=640, hop_length=200, n_mels=128, n_mfcc=20, sr=22050, pad_mode="reflect", window="hamming"),
+    dict(n_fft=640, hop_length=640, n_mels=23, n_mfcc=13, sr=16000, center=False, power=1.0),
 ])
 def test_fft_and_dense_dft_kernels_agree(gpu, kw, monkeypatch):
     """The in-register FFT kernel and the dense-DFT kernel are independent implementations of the

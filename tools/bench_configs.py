@@ -110,7 +110,9 @@ def main():
     asr320 = S.make_config(sr=16000, n_fft=320, hop_length=160, n_mels=80, n_mfcc=13)
     results["extra_nfft320"] = run(asr320, pcm, so, steps=10, warmup=2)
     asr640 = S.make_config(sr=16000, n_fft=640, hop_length=160, n_mels=80, n_mfcc=13)
-    results["extra_nfft640_dense_dft"] = run(asr640, pcm, so, steps=5, warmup=2)
+    results["extra_nfft640"] = run(asr640, pcm, so, steps=10, warmup=2)
+    asr600 = S.make_config(sr=16000, n_fft=600, hop_length=160, n_mels=80, n_mfcc=13)
+    results["extra_nfft600_dense_dft"] = run(asr600, pcm, so, steps=5, warmup=2)
     del pcm
 
     pcm5, so5 = make_batch(args.hours, 5, dev, lo_s=30.0, hi_s=60.0)

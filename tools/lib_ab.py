@@ -3,7 +3,7 @@
 events) of each library for one configuration, every library in a fresh child process, the whole
 list repeated so that drift between runs shows.
 
-    python tools/lib_ab.py <ref|asr512|asr400|fft1024> <hours> lib1.so[:VAR=VALUE[:VAR=VALUE...]] [lib2.so ...]
+    python tools/lib_ab.py <ref|asr512|asr400|asr480|asr320|asr640|fft1024> <hours> lib1.so[:VAR=VALUE[:VAR=VALUE...]] [lib2.so ...]
 
 A library may be followed by environment settings for its run (e.g. build/ab/x.so:MFCC_HIP_FAST=1)."""
 
@@ -26,6 +26,7 @@ cfg = {"ref": S.MfccConfig.reference_default(),
        "asr400": S.make_config(sr=16000, n_fft=400, hop_length=160, n_mels=80, n_mfcc=13),
        "fft1024": S.make_config(sr=16000, n_fft=1024, hop_length=256, n_mels=80, n_mfcc=13),
        "asr480": S.make_config(sr=16000, n_fft=480, hop_length=160, n_mels=80, n_mfcc=13),
+       "asr640": S.make_config(sr=16000, n_fft=640, hop_length=160, n_mels=80, n_mfcc=13),
        "asr320": S.make_config(sr=16000, n_fft=320, hop_length=160, n_mels=80, n_mfcc=13)}[which]
 dev = torch.device('cuda', 0)
 pcm, so = make_batch(%f, 1234, dev)
