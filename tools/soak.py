@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak of the front-end kernels: random configurations and ragged batches, each run
-twice (must be bit-identical) and cross-checked -- the in-register FFT kernels against the
+twice (must be bit-identical), batches on the int16 grid also through the int16 entry point (must be
+bit-identical too), and cross-checked -- the in-register FFT kernels against the
 dense-DFT kernel (an independent implementation), the 2048-point kernel against the CPU oracle on
 one utterance of the batch.
 
@@ -51,7 +52,8 @@ def soak(seconds: float, seed: int, max_batches: int = 0):
         lo = n_fft if not kw["center"] else 1
         lens = [int(rng.integers(lo, lo + int(rng.choice([10, 3000, 60000])))) for _ in range(n_utts)]
         ys = [(rng.standard_normal(L) * rng.choice([1e-3, 0.1, 1.0])).astype(np.float32) for L in lens]
-        if rng.random() < 0.3:
+        on_grid = rng.random() < 0.3
+        if on_grid:
             ys = [np.rint(np.clip(y, -0.99, 0.99) * 32767).astype(np.int16).astype(np.float32) / 32768.0 for y in ys]
         so = np.zeros(n_utts + 1, dtype=np.int64)
         np.cumsum(lens, out=so[1:])
@@ -61,6 +63,11 @@ def soak(seconds: float, seed: int, max_batches: int = 0):
         a, fo = run(plan, pcm, so)
         b, _ = run(plan, pcm, so)
         assert np.array_equal(a, b), f"not deterministic: {kw}"
+        if on_grid:
+            # the same samples as 16-bit PCM through the int16 entry point: bit-identical
+            pcm16 = torch.from_numpy(np.concatenate([np.rint(y * 32768.0).astype(np.int16) for y in ys])).to(dev)
+            c16, _ = run(plan, pcm16, so)
+            assert np.array_equal(a, c16), f"int16 entry point differs: {kw}"
         assert np.isfinite(a).all(), f"non-finite output: {kw}"
         if plan.front_kernel != "fft2048":
             os.environ["MFCC_HIP_DENSE_DFT"] = "1"
