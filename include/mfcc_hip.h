@@ -214,6 +214,14 @@ int mfcc_cmvn_apply(float* d_feats, int64_t n_rows, int32_t n_mfcc, const double
 int mfcc_to_db(const float* d_in, int64_t n, int32_t amplitude, float ref, int32_t ref_is_max, float amin,
                float top_db, float* d_out, void* d_workspace, void* stream);
 
+/* ---- MFCC of a log-mel spectrogram that already exists ------------------------------------- */
+/* The S= form of librosa.feature.mfcc (the reference's call at /root/reference/src/preprocess.py:134
+ * passes y; librosa's other spelling of the same function takes the dB-scaled mel spectrogram):
+ * scipy.fftpack.dct of the plan's type and norm along the mel axis, the first n_mfcc coefficients,
+ * the plan's lifter.  d_logmel is (rows, n_mels) row-major -- a frame per row, as mfcc_execute's
+ * output is (rows, n_mfcc) -- and n_mels is the plan's.  Asynchronous on `stream`. */
+int mfcc_dct(const mfcc_plan* plan, const float* d_logmel, int64_t rows, float* d_out, void* stream);
+
 /* ---- delta features (extension; the reference trains on the plain MFCCs) ------------------ */
 /* librosa.feature.delta(data, width, order, axis=time, mode='interp') on the concatenated
  * (total_frames, n_coef) features of a ragged batch, every utterance on its own: the order-th

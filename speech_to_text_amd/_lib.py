@@ -101,6 +101,7 @@ SYMBOLS = {
     "mfcc_plan_front_kernel": (C.c_char_p, [C.c_void_p]),
     "mfcc_to_db": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_float,
                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mfcc_dct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mfcc_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                              C.c_void_p, C.c_void_p]),
     "mfcc_host_pcm16_from_float": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),

@@ -316,6 +316,58 @@ __global__ __launch_bounds__(256) void k_db_dct_small(const DbDctArgs a) {
     }
 }
 
+// DCT (+ lifter) of rows that are already in dB: the S= form of librosa.feature.mfcc.  One
+// wavefront per 16 rows, the contraction of k_db_dct without the logarithm.
+__global__ __launch_bounds__(256) void k_dct_rows(const float* __restrict__ logmel, int64_t rows,
+                                                  const float* __restrict__ dct_frag,
+                                                  const float* __restrict__ lifter, float* __restrict__ out,
+                                                  int n_mels, int n_mels_pad, int n_mfcc, int n_rt) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * TILE_FRAMES;
+    if (r0 >= rows) return;
+    const int nvalid = (int)min((int64_t)TILE_FRAMES, rows - r0);
+    const int f = lane & 15, kq = lane >> 4;
+    const float* mrow = logmel + (r0 + min(f, nvalid - 1)) * n_mels;
+    const int steps_total = n_mels_pad / 4;
+    for (int rt0 = 0; rt0 < n_rt; rt0 += 4) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int c = 0; c < n_mels_pad / 64; ++c) {
+            float L[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 64 * c + 16 * j + 4 * kq + i;
+                    L[4 * j + i] = k < n_mels ? mrow[k] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (rt0 + r < n_rt) {
+                    const float* fr = dct_frag + ((size_t)(rt0 + r) * steps_total + 16 * c) * 64 + lane;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[s * 64], L[s], acc[r], 0, 0, 0);
+                }
+            }
+        }
+        if (f < nvalid) {
+            float* orow = out + (r0 + f) * n_mfcc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cidx = (rt0 + r) * 16 + 4 * kq + i;
+                    if (cidx < n_mfcc) orow[cidx] = acc[r][i] * lifter[cidx];
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // CMVN statistics (extension)
 // ------------------------------------------------------------------------------------------
@@ -1413,6 +1465,21 @@ int mfcc_to_db(const float* d_in, int64_t n, int32_t amplitude, float ref, int32
     if (top_db >= 0.0f || ref_is_max)
         hipLaunchKernelGGL(k_to_db_max, dim3(blocks), dim3(256), 0, st, d_in, n, amplitude, gmax);
     hipLaunchKernelGGL(k_to_db, dim3(blocks), dim3(256), 0, st, d_in, n, amplitude, r, ref_is_max, am, top_db, gmax, d_out);
+    HIP_TRY(hipGetLastError());
+    return MFCC_OK;
+}
+
+int mfcc_dct(const mfcc_plan* plan, const float* d_logmel, int64_t rows, float* d_out, void* stream) {
+    if (!plan) return fail(MFCC_E_INVALID, "plan is NULL");
+    if (rows < 0) return fail(MFCC_E_INVALID, "rows must be non-negative");
+    if (rows == 0) return MFCC_OK;
+    if (!d_logmel || !d_out) return fail(MFCC_E_INVALID, "NULL buffer");
+    if (rows > 0x7fffffffLL * 16) return fail(MFCC_E_UNSUPPORTED, "batch too large: split it");
+    HIP_TRY(hipSetDevice(plan->device));
+    const int64_t tiles = (rows + TILE_FRAMES - 1) / TILE_FRAMES;
+    hipLaunchKernelGGL(k_dct_rows, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       d_logmel, rows, plan->d_dct_frag, plan->d_lifter, d_out, plan->r.c.n_mels, plan->n_mels_pad,
+                       plan->r.c.n_mfcc, plan->n_rt);
     HIP_TRY(hipGetLastError());
     return MFCC_OK;
 }

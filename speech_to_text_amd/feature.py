@@ -80,6 +80,18 @@ class MfccPlan:
             _lib.check(n)
         return np.array(a[:n], dtype=np.float32), np.array(b[:n], dtype=np.float32)
 
+    def dct_rows(self, logmel: torch.Tensor) -> torch.Tensor:
+        """DCT (the plan's type and norm), first n_mfcc coefficients and lifter of ``(rows, n_mels)``
+        dB-scaled mel rows on this plan's device: ``(rows, n_mfcc)``.  Asynchronous on the current
+        stream."""
+        assert logmel.dtype == torch.float32 and logmel.is_contiguous() and logmel.device == self.device
+        assert logmel.ndim == 2 and logmel.shape[1] == self.config.n_mels
+        out = torch.empty((logmel.shape[0], self.config.n_mfcc), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mfcc_dct(self._handle, logmel.data_ptr(), int(logmel.shape[0]), out.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream))
+        return out
+
     @property
     def front_kernel(self) -> str:
         """Which front-end kernel the plan runs: 'fft2048', 'fft256', 'fft320', 'fft400', 'fft480', 'fft512', 'fft640', 'fft1024' or 'dense_dft'."""
@@ -285,8 +297,9 @@ def mfcc(*, y=None, sr=22050, S=None, n_mfcc=20, dct_type=2, norm="ortho", lifte
     is taken over the whole array passed in (all channels).
     """
     if S is not None:
-        raise NotImplementedError("mfcc(S=...) is not on the reference's path "
-                                  "(/root/reference/src/preprocess.py:134 passes y)")
+        # librosa's other spelling: S is the dB-scaled mel spectrogram, (..., n_mels, n_frames);
+        # the melspectrogram keywords are not used
+        return _mfcc_of_logmel(S, sr, n_mfcc, dct_type, norm, lifter, device)
     if y is None:
         raise ParameterError("y must be given")
     y = _as_float_array(y)
@@ -298,6 +311,22 @@ def mfcc(*, y=None, sr=22050, S=None, n_mfcc=20, dct_type=2, norm="ortho", lifte
     F = int(fo[1] - fo[0]) if len(chans) else 0
     res = out.reshape(len(chans), F, config.n_mfcc).cpu().numpy()
     return res.transpose(0, 2, 1).reshape(lead + (config.n_mfcc, F))
+
+
+def _mfcc_of_logmel(S, sr, n_mfcc, dct_type, norm, lifter, device) -> np.ndarray:
+    """``scipy.fftpack.dct(S, axis=-2, type, norm)[..., :n_mfcc, :]`` and the lifter, on the GPU."""
+    S = np.asarray(S)
+    if S.ndim < 2:
+        raise ParameterError("S must have shape (..., n_mels, n_frames)")
+    n_mels, F = int(S.shape[-2]), int(S.shape[-1])
+    lead = tuple(S.shape[:-2])
+    config = make_config(sr=sr, n_mfcc=n_mfcc, dct_type=dct_type, norm=norm, lifter=lifter, n_mels=n_mels)
+    plan = get_plan(config, _device(device))
+    rows = int(np.prod(lead, dtype=np.int64)) * F
+    x = torch.from_numpy(np.ascontiguousarray(np.swapaxes(S, -1, -2), dtype=np.float32)).to(plan.device)
+    out = plan.dct_rows(x.reshape(rows, n_mels))
+    res = out.reshape(lead + (F, config.n_mfcc)).cpu().numpy()
+    return np.ascontiguousarray(np.swapaxes(res, -1, -2))
 
 
 def melspectrogram(*, y=None, sr=22050, device=None, validate=True, **kwargs) -> np.ndarray:

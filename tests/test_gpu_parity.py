@@ -436,3 +436,24 @@ def test_config5_long_utterances(S):
         assert np.abs(logmel - want_db).max() <= DB_TOL
     want_db = R.power_to_db(R.melspectrogram(y=click, n_fft=2048, hop_length=512))
     assert (want_db <= want_db.max() - 80.0 + 1e-3).mean() > 0.9     # the click sets the floor
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 57), (2, 40, 33), (80, 1), (3, 2, 23, 16)])
+@pytest.mark.parametrize("dct_type,norm,lifter", [(2, "ortho", 0), (2, None, 22), (1, None, 0), (3, "ortho", 5)])
+def test_mfcc_of_a_given_log_mel_spectrogram(S, shape, dct_type, norm, lifter):
+    """librosa.feature.mfcc(S=...): the DCT and lifter of a dB-scaled mel spectrogram the caller
+    already has (the spelling of /root/reference/src/preprocess.py:134's function that takes S)."""
+    rng = np.random.default_rng(11)
+    logmel = (rng.standard_normal(shape) * 20.0 - 30.0).astype(np.float32)
+    n_mfcc = min(13, shape[-2])
+    got = S.mfcc(S=logmel, n_mfcc=n_mfcc, dct_type=dct_type, norm=norm, lifter=lifter)
+    want = R.mfcc(S=logmel.astype(np.float64), n_mfcc=n_mfcc, dct_type=dct_type, norm=norm, lifter=lifter)
+    assert got.shape == want.shape == shape[:-2] + (n_mfcc, shape[-1]) and got.dtype == np.float32
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * np.abs(want).max())
+    # the same numbers as the y= form gives on its own log-mel spectrogram
+    if dct_type == 2 and norm == "ortho" and lifter == 0 and tuple(shape) == (128, 57):
+        y = speech_like(57 * 512 - 1, seed=5)
+        full = S.mfcc(y=y, n_mfcc=13)
+        via = S.mfcc(S=R.power_to_db(R.melspectrogram(y=y)), n_mfcc=13)
+        np.testing.assert_allclose(via, full, atol=DB_TOL)
