@@ -11,6 +11,7 @@
 //                                     DCT on v_mfma_f32_16x16x4_f32, lifter, (F, n_mfcc) store
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <utility>
 
 #include <cmath>
 #include <cstdio>
@@ -552,6 +553,10 @@ struct mfcc_plan {
     int fast_mode = 0;
     size_t fast_lds_bytes = 0;
     size_t front_lds_bytes = 0;
+    // the variant that takes int16 PCM: `front` itself, or (where that one has no int16 build:
+    // the hop-512 variants that keep samples in registers) the best one that has
+    FrontVariant front16{};
+    size_t front16_lds_bytes = 0;
     mfcc_host::SparseMel sm;       // generic kernel: lane = filter
     mfcc_host::MelJobs mj;         // 2048-point kernel: balanced jobs
     int n_rt = 0, n_mels_pad = 0;
@@ -677,10 +682,18 @@ int select_variant(mfcc_plan* p) {
     }
     p->front_lds_bytes = k2048::lds_bytes(p->front.waves, p->front.win, p->front.tw1, p->front.w64_regs,
                                          p->front.melw_lds ? melw_floats : 0);
-    for (auto fn : {p->front.fn, p->front.fn16}) {
-        if (!fn) continue;
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->front_lds_bytes);
+    p->front16 = p->front;
+    if (!p->front16.fn16) {
+        for (int cand : {10, 1, 11, 0})
+            if (usable(cand) && kFrontVariants[cand].fn16) { p->front16 = kFrontVariants[cand]; break; }
+        if (!p->front16.fn16) return fail(MFCC_E_UNSUPPORTED, "LDS budget exceeded");
+    }
+    p->front16_lds_bytes = k2048::lds_bytes(p->front16.waves, p->front16.win, p->front16.tw1, p->front16.w64_regs,
+                                           p->front16.melw_lds ? melw_floats : 0);
+    const std::pair<FrontFn, size_t> fns[] = {{p->front.fn, p->front_lds_bytes}, {p->front16.fn16, p->front16_lds_bytes}};
+    for (const auto& f : fns) {
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(f.first),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.second);
         if (e2 != hipSuccess) return fail(MFCC_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e2));
     }
     return MFCC_OK;
@@ -1138,8 +1151,6 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     int32_t* tile_off = reinterpret_cast<int32_t*>(ws + L.tile_off);
     uint32_t* gmax = reinterpret_cast<uint32_t*>(ws + L.gmax);
     Tile* tiles = reinterpret_cast<Tile*>(ws + L.tiles);
-    if (pcm16 && plan->fast2048 && !plan->front.fn16)
-        return fail(MFCC_E_UNSUPPORTED, "this kernel variant has no int16 build (unset MFCC_HIP_VARIANT)");
     if (plan->profiling) plan->ev = plan->ev_ring[plan->ev_count++ % mfcc_plan::EV_RING];
 
     hipLaunchKernelGGL(k_prepare_scan, dim3(1), dim3(1024), 0, st, d_frame_offsets, n_utts, tile_off,
@@ -1218,7 +1229,7 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     }
     fa.pw_mode = plan->r.c.power == 2.0f ? 0 : (plan->r.c.power == 1.0f ? 1 : 2);
     fa.half_power = 0.5f * plan->r.c.power;
-    const FrontVariant& fv = plan->front;
+    const FrontVariant& fv = pcm16 ? plan->front16 : plan->front;
     const int64_t wg_needed = (L.ub_tiles * TILE_FRAMES + fv.waves - 1) / fv.waves;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(wg_needed, plan->n_cu));
     if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
@@ -1229,7 +1240,8 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
         HIP_TRY(hipGetLastError());
         return MFCC_OK;
     }
-    hipLaunchKernelGGL(pcm16 ? fv.fn16 : fv.fn, dim3(grid), dim3(fv.waves * 64), plan->front_lds_bytes, st, fa);
+    hipLaunchKernelGGL(pcm16 ? fv.fn16 : fv.fn, dim3(grid), dim3(fv.waves * 64),
+                       pcm16 ? plan->front16_lds_bytes : plan->front_lds_bytes, st, fa);
     if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[1], st));
     (void)total_frames;
     HIP_TRY(hipGetLastError());

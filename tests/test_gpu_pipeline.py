@@ -130,6 +130,12 @@ def test_asr_frontend_with_cmvn(gpu):
     dict(n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
     dict(n_fft=1024, hop_length=256, n_mfcc=13),
     dict(n_fft=256, hop_length=80, n_mels=40, n_mfcc=13, sr=8000),
+    dict(n_fft=640, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
+    # wide filters (4 Hz bins): the mel table no longer fits beside 16 wavefronts, and at hop 512
+    # the float path takes the variant that keeps samples in registers, which has no int16 build
+    dict(n_fft=2048, hop_length=512, n_mels=128, n_mfcc=13, sr=8000),
+    dict(n_fft=2048, hop_length=512, n_mels=80, n_mfcc=13, sr=8000),
+    dict(n_fft=2048, hop_length=512, n_mels=128, n_mfcc=13, sr=16000),
 ])
 def test_int16_pcm_ingest_is_bit_identical(gpu, kw):
     """16-bit PCM in (value / 32768, the waveform torchaudio decodes a LibriSpeech FLAC into for
