@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised soak of the front-end kernels: random configurations and ragged batches, each run
-twice (must be bit-identical), batches on the int16 grid also through the int16 entry point (must be
-bit-identical too), and cross-checked -- the in-register FFT kernels against the
+twice (must be bit-identical), through the no-allocation entry point and -- batches on the int16
+grid -- the int16 entry point (bit-identical too), some with utterances grouped under one top_db
+maximum, and cross-checked, spectrogram tap included -- the in-register FFT kernels against the
 dense-DFT kernel (an independent implementation), the 2048-point kernel against the CPU oracle on
 one utterance of the batch.
 
@@ -25,11 +26,40 @@ import speech_to_text_amd as S  # noqa: E402
 from oracle import mfcc_ref as R  # noqa: E402
 
 
-def run(plan, pcm, so):
+def run(plan, pcm, so, groups=None):
     fo = plan.frame_offsets(so)
     dev = pcm.device
-    out = plan.execute(pcm, torch.from_numpy(so).to(dev), torch.from_numpy(fo).to(dev), int(fo[-1]))
+    grp = torch.from_numpy(groups).to(dev) if groups is not None else None
+    out = plan.execute(pcm, torch.from_numpy(so).to(dev), torch.from_numpy(fo).to(dev), int(fo[-1]), group=grp)
     return out.cpu().numpy(), fo
+
+
+def run_noalloc(plan, pcm, so, groups=None):
+    """The same batch through mfcc_execute_noalloc (None when it does not fit the static scratch)."""
+    import ctypes as C
+
+    from speech_to_text_amd import _lib
+
+    fo = plan.frame_offsets(so)
+    dev = pcm.device
+    n, F = len(so) - 1, int(fo[-1])
+    if _lib.lib().mfcc_workspace_bytes(plan._handle, F, n) > _lib.NOALLOC_SCRATCH_BYTES:
+        return None
+    d_so, d_fo = torch.from_numpy(so).to(dev), torch.from_numpy(fo).to(dev)
+    grp = torch.from_numpy(groups).to(dev) if groups is not None else None
+    out = torch.empty((F, plan.config.n_mfcc), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().mfcc_execute_noalloc(plan._handle, pcm.data_ptr(), d_so.data_ptr(), d_fo.data_ptr(),
+                                               grp.data_ptr() if grp is not None else None, n, F, out.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream))
+    del C
+    return out.cpu().numpy()
+
+
+def run_spec(plan, pcm, so):
+    fo = plan.frame_offsets(so)
+    dev = pcm.device
+    out = plan.execute_spectrogram(pcm, torch.from_numpy(so).to(dev), torch.from_numpy(fo).to(dev), int(fo[-1]))
+    return out.cpu().numpy()
 
 
 def soak(seconds: float, seed: int, max_batches: int = 0):
@@ -74,13 +104,21 @@ def soak(seconds: float, seed: int, max_batches: int = 0):
         pcm = torch.from_numpy(np.concatenate(ys)).to(dev)
         os.environ.pop("MFCC_HIP_DENSE_DFT", None)
         plan = S.MfccPlan(cfg, dev)
-        a, fo = run(plan, pcm, so)
-        b, _ = run(plan, pcm, so)
+        # now and then neighbouring utterances share one top_db maximum (channels of one call)
+        groups = None
+        if n_fft != 2048 and rng.random() < 0.3:
+            groups = np.zeros(n_utts, dtype=np.int32)
+            for u in range(1, n_utts):
+                groups[u] = groups[u - 1] if rng.random() < 0.5 else u
+        a, fo = run(plan, pcm, so, groups)
+        b, _ = run(plan, pcm, so, groups)
         assert np.array_equal(a, b), f"not deterministic: {kw}"
+        na = run_noalloc(plan, pcm, so, groups)
+        assert na is None or np.array_equal(a, na), f"the no-allocation entry point differs: {kw}"
         if on_grid:
             # the same samples as 16-bit PCM through the int16 entry point: bit-identical
             pcm16 = torch.from_numpy(np.concatenate([np.rint(y * 32768.0).astype(np.int16) for y in ys])).to(dev)
-            c16, _ = run(plan, pcm16, so)
+            c16, _ = run(plan, pcm16, so, groups)
             assert np.array_equal(a, c16), f"int16 entry point differs: {kw}"
         assert np.isfinite(a).all(), f"non-finite output: {kw}"
         if plan.front_kernel != "fft2048":
@@ -88,7 +126,13 @@ def soak(seconds: float, seed: int, max_batches: int = 0):
             dense = S.MfccPlan(cfg, dev)
             os.environ.pop("MFCC_HIP_DENSE_DFT")
             assert dense.front_kernel == "dense_dft"
-            c, _ = run(dense, pcm, so)
+            c, _ = run(dense, pcm, so, groups)
+            if rng.random() < 0.25 and int(fo[-1]) * (1 + n_fft // 2) < 5e7:
+                # the |X|^power tap of both kernels: errors are relative to the frame's largest bin
+                sa, sc = run_spec(plan, pcm, so), run_spec(dense, pcm, so)
+                peak = np.maximum(sc.max(axis=1, keepdims=True), 1e-30)
+                rel = float((np.abs(sa - sc) / peak).max())
+                assert rel <= 2e-5 * max(1.0, kw.get("power", 2.0)), f"spectrogram taps differ by {rel} of the frame peak: {kw}"
             dense.close()
             # Utterances shorter than a frame under reflect padding are a few samples repeated: a
             # line spectrum whose inter-line bands hold nothing but window side lobes 50-80 dB down,
