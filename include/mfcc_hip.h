@@ -189,7 +189,7 @@ int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_
  * and read the per-kernel times afterwards.  No counterpart in the reference. */
 int mfcc_plan_timing_history(const mfcc_plan* plan, int32_t max_n, float* ms_front, float* ms_db_dct);
 /* Name of the front-end kernel the plan runs: "fft2048" (the reference's n_fft,
- * /root/reference/src/preprocess.py:134), "fft256", "fft320", "fft400", "fft480", "fft512", "fft640", "fft1024" (in-register FFTs for the
+ * /root/reference/src/preprocess.py:134), "fft256", "fft320", "fft400", "fft480", "fft512", "fft640", "fft800", "fft960", "fft1024" (in-register FFTs for the
  * short transforms of 16 kHz front ends) or "dense_dft" (any other even n_fft: the DFT as an fp32 MFMA
  * contraction).  A static string; NULL for a NULL plan.  No counterpart in the reference. */
 const char* mfcc_plan_front_kernel(const mfcc_plan* plan);

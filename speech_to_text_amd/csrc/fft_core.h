@@ -7,7 +7,7 @@
 //   rdft32 : 32-point DFT of a REAL sequence (bins 0..16) from one cfft16 of the packed
 //            sequence z[m] = r[2m] + i r[2m+1] plus the conjugate-symmetric split.
 //   rdft_cols<R> : the same for 2R = 4, 8, 16 points;  rdft25 : 25-point real DFT (5 x 5);
-//   rdft_even<A> : 20-, 30- and 40-point real DFTs, folded direct sums.
+//   rdft_even<A> : 20-, 30-, 40-, 50- and 60-point real DFTs, folded direct sums.
 //
 // Forward transform convention, as numpy.fft: X[k] = sum_n x[n] exp(-2 pi i n k / N).
 #pragma once
@@ -352,12 +352,65 @@ constexpr float S40[40] = {
     -1.0f, -0.9876883405951378f, -0.9510565162951536f, -0.891006524188368f, -0.8090169943749476f,
     -0.7071067811865477f, -0.5877852522924734f, -0.45399049973954697f, -0.3090169943749476f, -0.15643446504023112f};
 
+// cos, sin of 2 pi j / 50
+constexpr float C50[50] = {
+    1.0f, 0.9921147013144779f, 0.9685831611286311f, 0.9297764858882515f, 0.8763066800438636f,
+    0.8090169943749475f, 0.7289686274214116f, 0.6374239897486897f, 0.5358267949789965f, 0.42577929156507266f,
+    0.30901699437494745f, 0.18738131458572474f, 0.06279051952931353f, -0.0627905195293134f, -0.1873813145857246f,
+    -0.3090169943749471f, -0.4257792915650727f, -0.5358267949789969f, -0.6374239897486897f, -0.7289686274214113f,
+    -0.8090169943749473f, -0.8763066800438636f, -0.9297764858882513f, -0.968583161128631f, -0.9921147013144778f,
+    -1.0f, -0.9921147013144779f, -0.9685831611286312f, -0.9297764858882515f, -0.8763066800438635f,
+    -0.8090169943749478f, -0.7289686274214118f, -0.6374239897486895f, -0.5358267949789963f, -0.42577929156507216f,
+    -0.30901699437494756f, -0.18738131458572463f, -0.06279051952931321f, 0.06279051952931283f, 0.18738131458572427f,
+    0.30901699437494723f, 0.4257792915650718f, 0.5358267949789968f, 0.6374239897486893f, 0.7289686274214112f,
+    0.8090169943749473f, 0.8763066800438631f, 0.9297764858882515f, 0.968583161128631f, 0.9921147013144778f};
+constexpr float S50[50] = {
+    0.0f, 0.12533323356430426f, 0.2486898871648548f, 0.3681245526846779f, 0.4817536741017153f,
+    0.5877852522924731f, 0.6845471059286886f, 0.7705132427757893f, 0.8443279255020151f, 0.9048270524660196f,
+    0.9510565162951535f, 0.9822872507286886f, 0.9980267284282716f, 0.9980267284282716f, 0.9822872507286887f,
+    0.9510565162951536f, 0.9048270524660195f, 0.844327925502015f, 0.7705132427757893f, 0.6845471059286888f,
+    0.5877852522924732f, 0.4817536741017152f, 0.36812455268467814f, 0.24868988716485524f, 0.12533323356430454f,
+    0.0f, -0.12533323356430429f, -0.24868988716485457f, -0.3681245526846779f, -0.4817536741017154f,
+    -0.5877852522924727f, -0.6845471059286884f, -0.7705132427757894f, -0.8443279255020153f, -0.9048270524660198f,
+    -0.9510565162951535f, -0.9822872507286887f, -0.9980267284282716f, -0.9980267284282716f, -0.9822872507286887f,
+    -0.9510565162951536f, -0.9048270524660199f, -0.844327925502015f, -0.7705132427757896f, -0.684547105928689f,
+    -0.5877852522924734f, -0.4817536741017161f, -0.36812455268467786f, -0.24868988716485535f, -0.12533323356430465f};
+// cos, sin of 2 pi j / 60
+constexpr float C60[60] = {
+    1.0f, 0.9945218953682733f, 0.9781476007338057f, 0.9510565162951535f, 0.9135454576426009f,
+    0.8660254037844387f, 0.8090169943749475f, 0.7431448254773942f, 0.6691306063588582f, 0.5877852522924731f,
+    0.5000000000000001f, 0.4067366430758004f, 0.30901699437494745f, 0.20791169081775923f, 0.10452846326765346f,
+    0.0f, -0.10452846326765333f, -0.20791169081775934f, -0.30901699437494734f, -0.40673664307580004f,
+    -0.4999999999999998f, -0.587785252292473f, -0.6691306063588579f, -0.743144825477394f, -0.8090169943749473f,
+    -0.8660254037844387f, -0.913545457642601f, -0.9510565162951535f, -0.9781476007338057f, -0.9945218953682734f,
+    -1.0f, -0.9945218953682734f, -0.9781476007338057f, -0.9510565162951536f, -0.9135454576426009f,
+    -0.8660254037844388f, -0.8090169943749476f, -0.7431448254773942f, -0.6691306063588585f, -0.5877852522924732f,
+    -0.5000000000000004f, -0.4067366430758009f, -0.30901699437494756f, -0.2079116908177598f, -0.10452846326765423f,
+    0.0f, 0.10452846326765299f, 0.20791169081775943f, 0.30901699437494723f, 0.40673664307579976f,
+    0.5000000000000001f, 0.5877852522924729f, 0.6691306063588585f, 0.7431448254773942f, 0.8090169943749473f,
+    0.8660254037844388f, 0.913545457642601f, 0.9510565162951535f, 0.9781476007338057f, 0.9945218953682733f};
+constexpr float S60[60] = {
+    0.0f, 0.10452846326765346f, 0.20791169081775931f, 0.3090169943749474f, 0.40673664307580015f,
+    0.49999999999999994f, 0.5877852522924731f, 0.6691306063588582f, 0.7431448254773941f, 0.8090169943749475f,
+    0.8660254037844386f, 0.9135454576426009f, 0.9510565162951535f, 0.9781476007338057f, 0.9945218953682733f,
+    1.0f, 0.9945218953682734f, 0.9781476007338057f, 0.9510565162951536f, 0.913545457642601f,
+    0.8660254037844387f, 0.8090169943749475f, 0.7431448254773945f, 0.6691306063588583f, 0.5877852522924732f,
+    0.49999999999999994f, 0.40673664307580004f, 0.3090169943749475f, 0.20791169081775931f, 0.10452846326765329f,
+    0.0f, -0.10452846326765305f, -0.20791169081775907f, -0.3090169943749473f, -0.4067366430758002f,
+    -0.4999999999999997f, -0.587785252292473f, -0.6691306063588582f, -0.743144825477394f, -0.8090169943749473f,
+    -0.8660254037844384f, -0.9135454576426005f, -0.9510565162951535f, -0.9781476007338056f, -0.9945218953682733f,
+    -1.0f, -0.9945218953682734f, -0.9781476007338056f, -0.9510565162951536f, -0.9135454576426011f,
+    -0.8660254037844386f, -0.8090169943749476f, -0.743144825477394f, -0.6691306063588581f, -0.5877852522924734f,
+    -0.49999999999999967f, -0.40673664307580015f, -0.3090169943749476f, -0.20791169081775898f, -0.10452846326765342f};
+
 template <int A> struct TrigTable;
 template <> struct TrigTable<20> { static constexpr const float* c() { return C20; } static constexpr const float* s() { return S20; } };
 template <> struct TrigTable<30> { static constexpr const float* c() { return C30; } static constexpr const float* s() { return S30; } };
 template <> struct TrigTable<40> { static constexpr const float* c() { return C40; } static constexpr const float* s() { return S40; } };
+template <> struct TrigTable<50> { static constexpr const float* c() { return C50; } static constexpr const float* s() { return S50; } };
+template <> struct TrigTable<60> { static constexpr const float* c() { return C60; } static constexpr const float* s() { return S60; } };
 
-// Real A-point DFT for even A (20, 30, 40), bins 0 .. A/2: Y[c] = sum_a x[a] exp(-2 pi i a c / A), by
+// Real A-point DFT for even A (20, 30, 40, 50, 60), bins 0 .. A/2: Y[c] = sum_a x[a] exp(-2 pi i a c / A), by
 // the direct sum folded twice.  With H = A/2, p[a] = x[a] + x[A-a] and q[a] = x[a] - x[A-a]
 // (a = 1 .. H-1),
 //     Re Y[c] = x[0] + (-1)^c x[H] + sum_a p[a] cos(2 pi a c / A),   Im Y[c] = -sum_a q[a] sin(2 pi a c / A);

@@ -1,6 +1,6 @@
-// Front end for n_fft = 16 A with A = 20, 25, 30, 40 (n_fft = 320, 400, 480, 640: the 20, 25, 30
-// and 40 ms windows of 16 kHz speech front ends taken as the transform length, e.g. n_fft = 400,
-// hop 160, 80 mels) on gfx950: one wavefront per four consecutive frames, no barriers in the
+// Front end for n_fft = 16 A with A = 20, 25, 30, 40, 50, 60 (n_fft = 320, 400, 480, 640, 800, 960:
+// the 20 .. 60 ms windows of 16 kHz speech front ends -- or 25 / 20 ms ones at 32 / 48 kHz -- taken
+// as the transform length, e.g. n_fft = 400, hop 160, 80 mels) on gfx950: one wavefront per four consecutive frames, no barriers in the
 // frame loop.
 //
 //   pad / frame / window -> N-point real DFT (A x 16) -> |X|^power -> sparse mel filterbank
@@ -29,7 +29,7 @@
 #include "front_pow2.h"
 
 #ifndef MFCC_16A_WIN_LDS
-#define MFCC_16A_WIN_LDS ((1ULL << 30) | (1ULL << 40))
+#define MFCC_16A_WIN_LDS ((1ULL << 30) | (1ULL << 40) | (1ULL << 50) | (1ULL << 60))
 #endif
 
 namespace k16a {
@@ -37,7 +37,8 @@ constexpr int T = 4;                    // frames per wavefront pass
 constexpr int COL = 36;                 // floats per exchange column: 16 complex + 4 floats of padding
 template <int A>
 struct Geo {
-    static_assert(A == 20 || A == 25 || A == 30 || A == 40, "supported: n_fft = 320, 400, 480, 640");
+    static_assert(A == 20 || A == 25 || A == 30 || A == 40 || A == 50 || A == 60,
+                  "supported: n_fft = 320, 400, 480, 640, 800, 960");
     static constexpr int N = 16 * A, NB = N / 2 + 1, NA = A, NC = A / 2 + 1;   // NC columns per frame
     static constexpr int ROUNDS = (T * NC + 63) / 64;                          // step-2 columns per lane
     static_assert(ROUNDS <= 2, "at most two columns per lane");
@@ -51,7 +52,7 @@ struct Geo {
     // The window: A registers per lane, or (bit A of MFCC_16A_WIN_LDS) a table in LDS as [b][a],
     // rows WIN_ROW floats apart -- a multiple of 4 whose quarter is odd, so that the 16-byte reads
     // of the 16 residues b fall into 16 different bank groups.  Default: LDS at A = 30, where the
-    // 30 registers are what the kernel spills, and at A = 40.
+    // 30 registers are what the kernel spills, and at A >= 40.
     static constexpr bool WIN_LDS = ((unsigned long long)(MFCC_16A_WIN_LDS) >> A) & 1;
     static constexpr int WIN_ROW = ((A + 3) / 4) % 2 ? (A + 3) / 4 * 4 : (A + 3) / 4 * 4 + 4;
     static constexpr int WIN_FLOATS = WIN_LDS ? 16 * WIN_ROW : 0;

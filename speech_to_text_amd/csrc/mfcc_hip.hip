@@ -710,14 +710,17 @@ Pow2Fn k16a_pick(bool pw2, bool pcm16) {
     if (pw2) return pcm16 ? k_melspec_16a<A, W, 0, true> : k_melspec_16a<A, W, 0, false>;
     return pcm16 ? k_melspec_16a<A, W, 1, true> : k_melspec_16a<A, W, 1, false>;
 }
-// small_fft: 8, 9, 10 for the power-of-two kernels; 320, 400, 480, 640 for the 16 A kernels
-// (front_400.h; at 640 the regions are 12 KB and 12 wavefronts are the most that fit)
+// small_fft: 8, 9, 10 for the power-of-two kernels; 320, 400, 480, 640, 800, 960 for the 16 A kernels
+// (front_400.h; at 640 the regions are 12 KB and 12 wavefronts are the most that fit, at 800 and
+// 960 eight)
 Pow2Fn pow2_kernel(const mfcc_plan* p, bool pcm16) {
     const bool pw2 = p->r.c.power == 2.0f;
     if (p->small_fft == 320) return p->p2_waves == 16 ? k16a_pick<20, 16>(pw2, pcm16) : k16a_pick<20, 8>(pw2, pcm16);
     if (p->small_fft == 400) return p->p2_waves == 16 ? k16a_pick<25, 16>(pw2, pcm16) : k16a_pick<25, 8>(pw2, pcm16);
     if (p->small_fft == 480) return p->p2_waves == 16 ? k16a_pick<30, 16>(pw2, pcm16) : k16a_pick<30, 8>(pw2, pcm16);
     if (p->small_fft == 640) return p->p2_waves == 12 ? k16a_pick<40, 12>(pw2, pcm16) : k16a_pick<40, 8>(pw2, pcm16);
+    if (p->small_fft == 800) return k16a_pick<50, 8>(pw2, pcm16);
+    if (p->small_fft == 960) return k16a_pick<60, 8>(pw2, pcm16);
     if (p->small_fft == 8) return p->p2_waves == 16 ? pow2_pick<8, 16>(pw2, pcm16) : pow2_pick<8, 8>(pw2, pcm16);
     if (p->small_fft == 9) return p->p2_waves == 16 ? pow2_pick<9, 16>(pw2, pcm16) : pow2_pick<9, 8>(pw2, pcm16);
     return p->p2_waves == 16 ? pow2_pick<10, 16>(pw2, pcm16) : pow2_pick<10, 8>(pw2, pcm16);
@@ -823,7 +826,7 @@ bool build_16a_tables(mfcc_plan* p, const std::vector<float>& basis, std::vector
     p->p2_waves = 0;
     const char* force = std::getenv("MFCC_HIP_P2_WAVES");      // experiments: 8, 12 (A = 40 only) or 16
     for (int w : {16, 12, 8})
-        if ((w != 12 || A == 40) && (w != 16 || A != 40) && (!force || std::atoi(force) == w) &&
+        if ((w != 12 || A == 40) && (w != 16 || A < 40) && (!force || std::atoi(force) == w) &&
             G::lds_bytes(w, p->p2_quads, p->p2_rounds) <= (size_t)k2048::LDS_LIMIT) {
             p->p2_waves = w;
             break;
@@ -1010,7 +1013,7 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         for (size_t i = 0; i < jobs.size(); ++i)
             jobs[i] = make_int2(4 * p->mj.at[i], 4 * (k2048::MCELL_OFF + p->mj.cell[i]) | (p->mj.cont[i] ? 1 : 0));
     }
-    // n_fft 256 / 320 / 400 / 480 / 512 / 640 / 1024: the in-register FFT kernels (MFCC_HIP_DENSE_DFT=1 keeps the dense-DFT one)
+    // n_fft 256 / 320 / 400 / 480 / 512 / 640 / 800 / 960 / 1024: the in-register FFT kernels (MFCC_HIP_DENSE_DFT=1 keeps the dense-DFT one)
     std::vector<float2> p2_tw1;
     std::vector<float4> p2_melw;
     std::vector<uint2> p2_pairs;
@@ -1019,6 +1022,8 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         if (r.c.n_fft == 400 && build_16a_tables<25>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 400;
         if (r.c.n_fft == 480 && build_16a_tables<30>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 480;
         if (r.c.n_fft == 640 && build_16a_tables<40>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 640;
+        if (r.c.n_fft == 800 && build_16a_tables<50>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 800;
+        if (r.c.n_fft == 960 && build_16a_tables<60>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 960;
         if (r.c.n_fft == 256 && build_pow2_tables<8>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 8;
         if (r.c.n_fft == 512 && build_pow2_tables<9>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 9;
         if (r.c.n_fft == 1024 && build_pow2_tables<10>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 10;
@@ -1409,6 +1414,8 @@ const char* mfcc_plan_front_kernel(const mfcc_plan* plan) {
     if (plan->small_fft == 400) return "fft400";
     if (plan->small_fft == 480) return "fft480";
     if (plan->small_fft == 640) return "fft640";
+    if (plan->small_fft == 800) return "fft800";
+    if (plan->small_fft == 960) return "fft960";
     if (plan->small_fft == 8) return "fft256";
     if (plan->small_fft == 9) return "fft512";
     if (plan->small_fft == 10) return "fft1024";

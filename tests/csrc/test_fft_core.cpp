@@ -72,6 +72,8 @@ int main() {
     worst = fmax(worst, check_rdft_even<20>());
     worst = fmax(worst, check_rdft_even<30>());
     worst = fmax(worst, check_rdft_even<40>());
+    worst = fmax(worst, check_rdft_even<50>());
+    worst = fmax(worst, check_rdft_even<60>());
     worst = fmax(worst, check_rdft_cols<2>());
     worst = fmax(worst, check_rdft_cols<4>());
     worst = fmax(worst, check_rdft_cols<8>());

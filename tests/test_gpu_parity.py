@@ -86,6 +86,8 @@ def test_reference_default_one_utterance(S):
     dict(n_fft=480, hop_length=240, n_mels=128, sr=22050, pad_mode="reflect"),
     dict(n_fft=640, hop_length=160, n_mels=40, sr=16000),          # 40 x 16 in-register kernel
     dict(n_fft=640, hop_length=320, n_mels=128, sr=22050, pad_mode="reflect"),
+    dict(n_fft=800, hop_length=200, n_mels=80, sr=16000),          # 50 x 16
+    dict(n_fft=960, hop_length=480, n_mels=64, sr=48000, pad_mode="reflect"),   # 60 x 16
     dict(n_fft=600, hop_length=150, n_mels=40, sr=16000),          # dense-DFT kernel
     dict(n_fft=512, hop_length=160, n_mels=10, sr=16000),          # wide filters on the 512-point kernel
     dict(n_fft=1024, hop_length=256, n_mels=256, sr=44100),        # 16 mel rounds of 32 filters
@@ -127,7 +129,7 @@ def test_mfcc_parity(S, kw):
     np.testing.assert_allclose(got, want, rtol=0, atol=DB_TOL)
 
 
-@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160), (512, 128), (1024, 256), (256, 64), (480, 160), (320, 80), (640, 160)])
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160), (512, 128), (1024, 256), (256, 64), (480, 160), (320, 80), (640, 160), (800, 200), (960, 240)])
 def test_spectrogram_parity(S, n_fft, hop):
     y = speech_like(30000, seed=4)
     want = np.abs(R.stft(y, n_fft=n_fft, hop_length=hop)) ** 2

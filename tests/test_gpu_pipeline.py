@@ -131,6 +131,7 @@ def test_asr_frontend_with_cmvn(gpu):
     dict(n_fft=1024, hop_length=256, n_mfcc=13),
     dict(n_fft=256, hop_length=80, n_mels=40, n_mfcc=13, sr=8000),
     dict(n_fft=640, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
+    dict(n_fft=960, hop_length=480, n_mels=80, n_mfcc=13, sr=48000),
     # wide filters (4 Hz bins): the mel table no longer fits beside 16 wavefronts, and at hop 512
     # the float path takes the variant that keeps samples in registers, which has no int16 build
     dict(n_fft=2048, hop_length=512, n_mels=128, n_mfcc=13, sr=8000),
@@ -170,6 +171,8 @@ def test_int16_pcm_ingest_is_bit_identical(gpu, kw):
     (dict(n_fft=320, hop_length=160, n_mels=40, sr=16000), "fft320"),
     (dict(n_fft=480, hop_length=160, n_mels=80, sr=16000), "fft480"),
     (dict(n_fft=640, hop_length=160, n_mels=80, sr=16000), "fft640"),
+    (dict(n_fft=800, hop_length=320, n_mels=80, sr=32000), "fft800"),
+    (dict(n_fft=960, hop_length=480, n_mels=80, sr=48000), "fft960"),
     (dict(n_fft=600, hop_length=150, n_mels=80, sr=16000), "dense_dft"),
 ])
 def test_front_kernel_selection(gpu, kw, name):
@@ -198,6 +201,10 @@ def test_front_kernel_selection(gpu, kw, name):
     dict(n_fft=640, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
     dict(n_fft=640, hop_length=200, n_mels=128, n_mfcc=20, sr=22050, pad_mode="reflect", window="hamming"),
     dict(n_fft=640, hop_length=640, n_mels=23, n_mfcc=13, sr=16000, center=False, power=1.0),
+    dict(n_fft=800, hop_length=200, n_mels=80, n_mfcc=13, sr=16000),
+    dict(n_fft=800, hop_length=333, n_mels=128, n_mfcc=20, sr=32000, pad_mode="reflect", window="hamming"),
+    dict(n_fft=960, hop_length=480, n_mels=80, n_mfcc=13, sr=48000),
+    dict(n_fft=960, hop_length=960, n_mels=23, n_mfcc=13, sr=16000, center=False, power=1.0),
 ])
 def test_fft_and_dense_dft_kernels_agree(gpu, kw, monkeypatch):
     """The in-register FFT kernel and the dense-DFT kernel are independent implementations of the

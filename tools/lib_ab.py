@@ -27,6 +27,8 @@ cfg = {"ref": S.MfccConfig.reference_default(),
        "fft1024": S.make_config(sr=16000, n_fft=1024, hop_length=256, n_mels=80, n_mfcc=13),
        "asr480": S.make_config(sr=16000, n_fft=480, hop_length=160, n_mels=80, n_mfcc=13),
        "asr640": S.make_config(sr=16000, n_fft=640, hop_length=160, n_mels=80, n_mfcc=13),
+       "asr800": S.make_config(sr=16000, n_fft=800, hop_length=160, n_mels=80, n_mfcc=13),
+       "asr960": S.make_config(sr=16000, n_fft=960, hop_length=160, n_mels=80, n_mfcc=13),
        "asr320": S.make_config(sr=16000, n_fft=320, hop_length=160, n_mels=80, n_mfcc=13)}[which]
 dev = torch.device('cuda', 0)
 pcm, so = make_batch(%f, 1234, dev)

@@ -71,7 +71,7 @@ def soak(seconds: float, seed: int, max_batches: int = 0):
     n, worst, worst_kw = 0, 0.0, None
     used, t_say = {}, time.time() + 30.0
     while time.time() < t_end and not (max_batches and n >= max_batches):
-        n_fft = int(rng.choice([2048, 2048, 2048, 1024, 640, 512, 480, 400, 320, 256]))
+        n_fft = int(rng.choice([2048, 2048, 2048, 1024, 960, 800, 640, 512, 480, 400, 320, 256]))
         kw = dict(n_fft=n_fft, hop_length=int(rng.integers(n_fft // 8, n_fft + 1)), n_mels=int(rng.choice([20, 40, 64, 80, 128])),
                   n_mfcc=int(rng.choice([13, 20])), sr=int(rng.choice([8000, 16000, 22050])),
                   center=bool(rng.random() < 0.8), pad_mode=str(rng.choice(["constant", "reflect"])))
