@@ -46,18 +46,6 @@ __host__ __device__ constexpr int xch_slot(int k2, int c) {   // complex index o
 //   hit 64 different banks.
 //   the column-0 scratch (4 rows of 24 complex)
 //   the mel cells: rows of 64 partial sums (MelJobs in host_tables.h), the last row for idle jobs
-#ifndef MFCC_AB_QUAD_ASM
-#define MFCC_AB_QUAD_ASM 1
-#endif
-#ifndef MFCC_AB_WIN_PAIRS
-#define MFCC_AB_WIN_PAIRS 1
-#endif
-// Development only: compile-time removal of one piece of the frame loop (the results are then
-// garbage; only the kernel time is of interest).  1 mel stage, 2 sample loads, 4 window, 8 first
-// DFT-16 + split, 16 exchange, 32 quad DFT-4, 64 second DFT-16, 128 column-0 path, 256 power store
-#ifndef MFCC_ABL
-#define MFCC_ABL 0
-#endif
 constexpr int P_ROW_BINS = 64;
 constexpr int P_ROW = 80;
 constexpr int P_END = 16 * P_ROW + 16;            // bin 1024 sits at 1280; reads may run on to here
@@ -142,7 +130,6 @@ struct FrontArgs {
     int32_t pw_mode;         // 0: power 2, 1: power 1, 2: general
     int32_t pcm16;           // pcm holds int16 samples
     int32_t share;           // wavefronts that walk one run of frames together (1, 2, 4, 8 or 16)
-    int32_t ablate;          // development only: bit 0 skips the mel stage
     float half_power;        // power / 2
 };
 
@@ -298,15 +285,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
     // 32 values come in 8 conflict-free ds_read_b128 (4 LDS cycles each; 32 ds_read_b32 take 2 each,
     // and pairs of ds_read_b64 get merged into half-rate ds_read2st64_b64)
     if (WIN == IN_LDS) {
-#if MFCC_AB_WIN_PAIRS
         for (int i = tid; i < 512; i += THREADS) {
             const int j = i >> 6, l = i & 63;
             reinterpret_cast<float4*>(win_l)[i] = make_float4(a.window[l + 256 * j], a.window[l + 256 * j + 64],
                                                               a.window[l + 256 * j + 128], a.window[l + 256 * j + 192]);
         }
-#else
-        for (int i = tid; i < 2048; i += THREADS) win_l[i] = a.window[i];
-#endif
     }
     if (tid < WAVES) run_ctr[tid] = 0;
     if (MELW_LDS) {
@@ -495,34 +478,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
 #pragma unroll
                 for (int n2 = 0; n2 < 32; ++n2) src[n2] = PCM16_SCALE * (float)h[n2];
             } else if (HOPR == 0 || !raw_ok) {
-#if MFCC_ABL & 2
-#pragma unroll
-                for (int n2 = 0; n2 < 32; ++n2) src[n2] = (float)(lane + n2 + (int)row);
-#else
 #pragma unroll
                 for (int n2 = 0; n2 < 32; ++n2) src[n2] = pp[64 * n2];
-#endif
             }
-            if (MFCC_ABL & 4) {
-#pragma unroll
-                for (int n2 = 0; n2 < 32; ++n2) r[n2] = src[n2];
-            } else if (WIN == IN_REGS) {
+            if (WIN == IN_REGS) {
 #pragma unroll
                 for (int n2 = 0; n2 < 32; ++n2) r[n2] = src[n2] * win[n2];
             } else {
                 float wv[32];
                 if (WIN == IN_LDS) {
-#if MFCC_AB_WIN_PAIRS
                     const float4* wq = reinterpret_cast<const float4*>(__builtin_assume_aligned(win_l, 16)) + lane;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float4 w4 = wq[64 * j];
                         wv[4 * j] = w4.x; wv[4 * j + 1] = w4.y; wv[4 * j + 2] = w4.z; wv[4 * j + 3] = w4.w;
                     }
-#else
-#pragma unroll
-                    for (int n2 = 0; n2 < 32; ++n2) wv[n2] = win_l[lane + 64 * n2];
-#endif
                 } else {
                     // from global memory (the CU's vector cache): 8 loads of 16 bytes
                     const float4* wt = a.window_t + 8 * lane;
@@ -551,14 +521,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         }
 
         // ---- step 1: real DFT-32 over n2, twiddle, exchange ------------------------------------
-#if MFCC_ABL & 16
-        float xkeep_r[16], xkeep_i[16];
-#endif
         {
             float zr[16], zi[16];
 #pragma unroll
             for (int m = 0; m < 16; ++m) { zr[m] = r[2 * m]; zi[m] = r[2 * m + 1]; }
-            if (!(MFCC_ABL & 8)) fc::cfft16(zr, zi);
+            fc::cfft16(zr, zi);
             __builtin_amdgcn_sched_barrier(0);
             float2 tw[16];
             if (TW1 == IN_LDS) {
@@ -575,41 +542,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             }
             __builtin_amdgcn_sched_barrier(0);   // twiddle reads overlap the conjugate split
             float ar[16], ai[16];
-            if (!(MFCC_ABL & 8)) fc::rdft32_split(zr, zi, ar, ai);
-            else {
-#pragma unroll
-                for (int m = 0; m < 16; ++m) { ar[m] = zr[m]; ai[m] = zi[m]; }
-            }
-#if MFCC_ABL & 16
-#pragma unroll
-            for (int k2 = 1; k2 < 16; ++k2) fc::cmul(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
-#pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) { xkeep_r[k2] = ar[k2]; xkeep_i[k2] = ai[k2]; }
-#else
+            fc::rdft32_split<true>(zr, zi, ar, ai);      // ai[9..15] come negated
             X[y0_off] = ar[0];                   // y[n1]      = sum over even n2
             X[y1_off] = ai[0];                   // y[64 + n1] = sum over odd n2
 #pragma unroll
             for (int k2 = 1; k2 < 16; ++k2) {
-                fc::cmul(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
+                if (k2 <= 8) fc::cmul(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
+                else fc::cmul_nim(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
                 X2[k2 * COL_STRIDE + xw[k2 & 3]] = make_float2(ar[k2], ai[k2]);
             }
-#endif
         }
 
         // ---- step 2: quad DFT-4 (DPP), twiddle, DFT-16 over m -----------------------------------
         float dr[16], di[16];
         {
             float2 w6[16];
-#if MFCC_ABL & 16
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { dr[j] = xkeep_r[j]; di[j] = xkeep_i[j]; }
-#else
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float4 v = *reinterpret_cast<const float4*>(X + (xr_base ^ (4 * j)));
                 dr[2 * j] = v.x; di[2 * j] = v.y; dr[2 * j + 1] = v.z; di[2 * j + 1] = v.w;
             }
-#endif
             if (W64_REGS) {
 #pragma unroll
                 for (int m = 1; m < 16; ++m) w6[m] = w64r[m];
@@ -626,8 +578,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
                 }
             }
             __builtin_amdgcn_sched_barrier(0);   // all exchange + twiddle reads in flight
-#if MFCC_ABL & 32
-#elif MFCC_AB_QUAD_ASM
             quad_fmac8<2>(dr, sgn1); quad_fmac8<2>(dr + 8, sgn1);
             quad_fmac8<2>(di, sgn1); quad_fmac8<2>(di + 8, sgn1);
 #pragma unroll
@@ -638,20 +588,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             }
             quad_fmac8<1>(dr, sgn2); quad_fmac8<1>(dr + 8, sgn2);
             quad_fmac8<1>(di, sgn2); quad_fmac8<1>(di + 8, sgn2);
-#else
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float xr = fmaf(quad_swap2(dr[i]), sgn1, dr[i]);
-                const float xi = fmaf(quad_swap2(di[i]), sgn1, di[i]);
-                const float yr = lane3 ? -xi : xr;
-                const float yi = lane3 ? xr : xi;
-                dr[i] = fmaf(quad_swap1(yr), sgn2, yr);
-                di[i] = fmaf(quad_swap1(yi), sgn2, yi);
-            }
-#endif
 #pragma unroll
             for (int m = 1; m < 16; ++m) fc::cmul(dr[m], di[m], w6[m].x, w6[m].y);
-            if (!(MFCC_ABL & 64)) fc::cfft16(dr, di);
+            fc::cfft16(dr, di);
         }
 
         // ---- power spectrum -> LDS (natural bin order) -------------------------------------------
@@ -675,7 +614,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
                 cr[i] = dpp_row_shr<12, 0x8>(cr[i], dr[fc::cfft16_pos(4 * i + 3)]);
                 ci[i] = dpp_row_shr<12, 0x8>(ci[i], di[fc::cfft16_pos(4 * i + 3)]);
             }
-            if (lane < 16 && !(MFCC_ABL & 128)) {
+            if (lane < 16) {
                 float2* S = reinterpret_cast<float2*>(X + SPECIAL_OFF) + kb * SPECIAL_ROW + k2c;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) S[4 * i] = make_float2(cr[i], ci[i]);
@@ -687,8 +626,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             for (int ka = 0; ka < 16; ++ka) {
                 const float re = dr[fc::cfft16_pos(ka)], im = di[fc::cfft16_pos(ka)];
                 const float pw = apply_power<PW>(re * re + im * im, a.pw_mode, a.half_power);
-                if (MFCC_ABL & 256) { if (pw == 12345.0f) X[pb0] = pw; }
-                else if (ka < 8) X[pb0 + 2 * P_ROW * ka] = pw; else X[pb1 + 2 * P_ROW * (15 - ka)] = pw;
+                if (ka < 8) X[pb0 + 2 * P_ROW * ka] = pw; else X[pb1 + 2 * P_ROW * (15 - ka)] = pw;
             }
         }
         if (a.mel_out) {
@@ -697,10 +635,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         }
         // This lane's job descriptors are requested here so that they return while column 0
         // makes its round trip.
-        const bool mel_fast = MELW_LDS && n_jobs <= MEL_REG_JOBS && a.mel_out && !(a.ablate & 1) && !(MFCC_ABL & 1);
+        const bool mel_fast = MELW_LDS && n_jobs <= MEL_REG_JOBS && a.mel_out;
         uint4 jq = make_uint4(0u, 0u, 0u, 0u);
         if (mel_fast) jq = reinterpret_cast<const uint4*>(jobs_l)[lane];
-        if (!(MFCC_ABL & 128)) {
+        {
             // column 0: C = DFT-64 of c[r] = y[2r] + i y[2r+1]; Y[j] = E[j] + W_128^j O[j]
             const float2* S = reinterpret_cast<const float2*>(X + SPECIAL_OFF);
             const float2 cj = S[sj];
@@ -731,7 +669,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
         // outputs leave as coalesced rows.  (Filterbanks that would need more cell rows than
         // there are share one cell per filter through LDS atomics, which one wavefront executes
         // in program order, so that sum is deterministic too -- but slow.)
-        if (a.mel_out && !(a.ablate & 1) && !(MFCC_ABL & 1)) {
+        if (a.mel_out) {
             const int2* jp = (MELW_LDS ? jobs_l : a.mel_jobs) + lane;
             const float4* wp = (MELW_LDS ? melw_l : a.melw) + lane;
             char* Xb = reinterpret_cast<char*>(X);

@@ -30,6 +30,18 @@ constexpr size_t fast_lds_bytes(int waves, int n_jobs) {
 #ifndef MFCC_FAST_WINFOLD
 #define MFCC_FAST_WINFOLD 1
 #endif
+#ifndef MFCC_FAST_TW1Q
+#define MFCC_FAST_TW1Q 1
+#endif
+// experiment: issue priority per stage, two bits each: step 1 (bits 0-1), step 2 (2-3), power store and
+// column 0 (4-5), mel stage (6-7)
+#ifndef MFCC_FAST_PRIO
+#define MFCC_FAST_PRIO 0x54
+#endif
+#define MFCC_SETPRIO(stage)                                                                            \
+    do {                                                                                               \
+        if (MFCC_FAST_PRIO) __builtin_amdgcn_s_setprio((MFCC_FAST_PRIO >> (2 * (stage))) & 3);          \
+    } while (0)
 template <int WAVES, bool PCM16>
 __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArgs a) {
     using namespace k2048;
@@ -50,7 +62,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
     float2* X2 = reinterpret_cast<float2*>(X);
 
     for (int i = tid; i < WAVES * XCH_FLOATS; i += THREADS) regions[i] = 0.0f;
+#if MFCC_FAST_TW1Q
+    // step-1 twiddles as quads: float4 (j, lane) = {tw[2j+1][lane], tw[2j+2][lane]}, j = 0..6, then
+    // tw[15][lane] alone: seven 16-byte reads and one 8-byte read per frame (pairs of 8-byte reads
+    // get merged into ds_read2st64_b64, which takes twice the LDS cycles)
+    for (int i = tid; i < 15 * 64; i += THREADS) {
+        const int k2 = 1 + (i >> 6), l = i & 63;
+        const int j = (k2 - 1) >> 1;
+        tw1_l[j < 7 ? (j * 64 + l) * 2 + ((k2 - 1) & 1) : 7 * 128 + l] = a.tw1[i];
+    }
+#else
     for (int i = tid; i < 15 * 64; i += THREADS) tw1_l[i] = a.tw1[i];
+#endif
     if (tid < 64) {
         // W_64^(m kb), m = 1..15, at slot m - 1 of row kb: eight aligned 16-byte reads per row
         const int m = tid & 15;
@@ -166,18 +189,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
             cur_grp = tc.grp;
             runmax = 0.0f;
         }
-        // every path below gives smp new values before the frame uses them, so that the
-        // compiler does not keep last frame's 32 registers alive through this one
+        const int64_t row = tc.row0 + (t - tc.f0);
+        MFCC_SETPRIO(0);
+
+        // ---- samples, window, step 1: real DFT-32 over n2, twiddle, exchange -------------------------
+        // both paths give all 32 sample registers new values, so last frame's are dead here
         if (interior) {
             load_samples(tc.soff, t);
         } else {
-#pragma unroll
-            for (int n2 = 0; n2 < 32; ++n2) smp[n2] = 0.0f;
-        }
-        const int64_t row = tc.row0 + (t - tc.f0);
-
-        // ---- samples, window, step 1: real DFT-32 over n2, twiddle, exchange -------------------------
-        if (!interior) {
             stage_edge_frame(X, a.pcm, tc.soff, PCM16, t * a.hop - a.pad, tc.T, a.reflect, lane);
 #pragma unroll
             for (int n2 = 0; n2 < 32; ++n2) smp[n2] = X[lane + 64 * n2];
@@ -208,21 +227,36 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
 #endif
             __builtin_amdgcn_sched_barrier(0);
             float2 tw[16];
+#if MFCC_FAST_TW1Q
+            {
+                const float4* tq = reinterpret_cast<const float4*>(tw1_l) + lane;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const float4 v = tq[64 * j];
+                    tw[2 * j + 1] = make_float2(v.x, v.y);
+                    tw[2 * j + 2] = make_float2(v.z, v.w);
+                }
+                tw[15] = tw1_l[7 * 128 + lane];
+            }
+#else
 #pragma unroll
             for (int k2 = 1; k2 < 16; ++k2) tw[k2] = tw1_l[(k2 - 1) * 64 + lane];
+#endif
             __builtin_amdgcn_sched_barrier(0);
             float ar[16], ai[16];
-            fc::rdft32_split(zr, zi, ar, ai);
+            fc::rdft32_split<true>(zr, zi, ar, ai);      // ai[9..15] come negated
             X[y0_off] = ar[0];
             X[y1_off] = ai[0];
 #pragma unroll
             for (int k2 = 1; k2 < 16; ++k2) {
-                fc::cmul(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
+                if (k2 <= 8) fc::cmul(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
+                else fc::cmul_nim(ar[k2], ai[k2], tw[k2].x, tw[k2].y);
                 X2[k2 * COL_STRIDE + xw[k2 & 3]] = make_float2(ar[k2], ai[k2]);
             }
         }
 
         // ---- step 2: quad DFT-4 (DPP), twiddle, DFT-16 over m -----------------------------------
+        MFCC_SETPRIO(1);
         float dr[16], di[16];
         {
             float2 w6[16];
@@ -256,6 +290,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
         }
 
         // ---- power spectrum -> LDS (natural bin order) -------------------------------------------
+        MFCC_SETPRIO(2);
         {
             float cr[4], ci[4];
 #pragma unroll
@@ -301,6 +336,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
         }
 
         // ---- sparse mel filterbank: four jobs per lane (see front_2048.h) -------------------------
+        MFCC_SETPRIO(3);
         {
             const float4* wp = melw_l + lane;
             float chain = 0.0f;

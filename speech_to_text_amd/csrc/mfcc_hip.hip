@@ -10,6 +10,8 @@
 //   k_db_dct                          10 log10, top_db clamp against the utterance maximum,
 //                                     DCT on v_mfma_f32_16x16x4_f32, lifter, (F, n_mfcc) store
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -589,11 +591,17 @@ struct mfcc_plan {
     // optional per-kernel timing (mfcc_plan_set_profiling): a ring of event triples (before the
     // front end, after it, after dB+DCT), one triple per execute, so that a caller can run many
     // executes back to back and read all their times afterwards
+    // The plan is shared by threads and streams: an execute takes its ring slot with an atomic
+    // increment and carries the triple as a local; a slot counts only once all three of its events
+    // have been recorded (ev_done), so a failed launch leaves no half-recorded triple to be read.
     bool profiling = false;
     static constexpr int EV_RING = 256;
     hipEvent_t (*ev_ring)[3] = nullptr;
-    mutable int64_t ev_count = 0;                    // executes recorded since profiling was (re)enabled
-    mutable hipEvent_t* ev = nullptr;                // the triple of the execute being recorded
+    mutable std::atomic<int64_t> ev_count{0};        // executes that took a slot since profiling was (re)enabled
+    mutable std::atomic<int64_t>* ev_done = nullptr; // per slot: 1 + the execute number whose triple is complete, or 0
+    // switches for experiments, read from the environment once, when the plan is made
+    int share = 16;                                  // MFCC_HIP_SHARE: wavefronts that walk one run of frames together
+    int db_per_cu = 2;                               // MFCC_HIP_DB_GRID: dB + DCT workgroups per CU
     // the no-allocation entry point's workspace: this device's copy of the static scratch array
     void* static_scratch = nullptr;
 };
@@ -953,6 +961,10 @@ int mfcc_batch_layout(const mfcc_config* cfg, const int64_t* h_sample_offsets, i
 int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
     if (!out_plan) return fail(MFCC_E_INVALID, "out_plan is NULL");
     *out_plan = nullptr;
+    // librosa computes an odd-length transform; this library has no kernel for one -- a limit of
+    // the library, not an invalid parameter
+    if (cfg && cfg->struct_size == (int32_t)sizeof(mfcc_config) && cfg->n_fft >= 3 && cfg->n_fft % 2)
+        return fail(MFCC_E_UNSUPPORTED, "odd n_fft (" + std::to_string(cfg->n_fft) + ") has no kernel in this library");
     mfcc_host::Resolved r;
     const std::string e = mfcc_host::resolve(cfg, &r);
     if (!e.empty()) return fail(MFCC_E_INVALID, e);
@@ -971,6 +983,12 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         return fail(MFCC_E_HIP, std::string("no usable HIP device: ") + hipGetErrorString(he));
     }
     p->n_cu = prop.multiProcessorCount;
+    // experiment switches: read here, once, never on the execute path
+    if (const char* e = std::getenv("MFCC_HIP_SHARE")) {
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) p->share = v;
+    }
+    if (const char* e = std::getenv("MFCC_HIP_DB_GRID")) p->db_per_cu = std::max(1, std::atoi(e));
 
     std::vector<double> win;
     mfcc_host::build_window(r, win);
@@ -1139,6 +1157,7 @@ void mfcc_plan_destroy(mfcc_plan* p) {
         for (int i = 0; i < mfcc_plan::EV_RING; ++i)
             for (int j = 0; j < 3; ++j) if (p->ev_ring[i][j]) (void)hipEventDestroy(p->ev_ring[i][j]);
         delete[] p->ev_ring;
+        delete[] p->ev_done;
     }
     delete p;
 }
@@ -1148,15 +1167,35 @@ size_t mfcc_workspace_bytes(const mfcc_plan* plan, int64_t total_frames, int32_t
     return ws_layout(total_frames, n_utts, plan->r.c.n_mels, true).total;
 }
 
+// One execute's profiling slot: the event triple and the number it will be known by.
+struct ProfSlot {
+    hipEvent_t* ev = nullptr;
+    int64_t seq = 0;
+};
+static ProfSlot take_prof_slot(const mfcc_plan* plan) {
+    ProfSlot s;
+    if (!plan->profiling || !plan->ev_ring) return s;
+    s.seq = plan->ev_count.fetch_add(1, std::memory_order_relaxed);
+    const int slot = (int)(s.seq % mfcc_plan::EV_RING);
+    plan->ev_done[slot].store(0, std::memory_order_release);
+    s.ev = plan->ev_ring[slot];
+    return s;
+}
+static int finish_prof_slot(const mfcc_plan* plan, const ProfSlot& s, hipStream_t st) {
+    if (!s.ev) return MFCC_OK;
+    HIP_TRY(hipEventRecord(s.ev[2], st));
+    plan->ev_done[s.seq % mfcc_plan::EV_RING].store(s.seq + 1, std::memory_order_release);
+    return MFCC_OK;
+}
+
 static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, const int64_t* d_sample_offsets,
                         const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
                         int64_t total_frames, float* mel_out, float* spec_out, char* ws,
-                        const WsLayout& L, hipStream_t st) {
+                        const WsLayout& L, hipStream_t st, hipEvent_t* ev) {
     WsHeader* hdr = reinterpret_cast<WsHeader*>(ws + L.hdr);
     int32_t* tile_off = reinterpret_cast<int32_t*>(ws + L.tile_off);
     uint32_t* gmax = reinterpret_cast<uint32_t*>(ws + L.gmax);
     Tile* tiles = reinterpret_cast<Tile*>(ws + L.tiles);
-    if (plan->profiling) plan->ev = plan->ev_ring[plan->ev_count++ % mfcc_plan::EV_RING];
 
     hipLaunchKernelGGL(k_prepare_scan, dim3(1), dim3(1024), 0, st, d_frame_offsets, n_utts, tile_off,
                        gmax, hdr);
@@ -1179,9 +1218,9 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
         const int passes_per_tile = plan->small_fft >= 320 ? TILE_FRAMES / k16a::T : (1 << plan->small_fft) / 128;
         const int64_t wg_needed = (L.ub_tiles * passes_per_tile + plan->p2_waves - 1) / plan->p2_waves;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(wg_needed, plan->n_cu));
-        if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
+        if (ev) HIP_TRY(hipEventRecord(ev[0], st));
         hipLaunchKernelGGL(pow2_kernel(plan, pcm16), dim3(grid), dim3(plan->p2_waves * 64), plan->p2_lds_bytes, st, pa);
-        if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[1], st));
+        if (ev) HIP_TRY(hipEventRecord(ev[1], st));
         HIP_TRY(hipGetLastError());
         return MFCC_OK;
     }
@@ -1204,9 +1243,9 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)k2048::LDS_LIMIT / plan->g_lds_bytes));
         const int64_t n_super = (L.ub_tiles + nt - 1) / nt;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_super, (int64_t)plan->n_cu * per_cu));
-        if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
+        if (ev) HIP_TRY(hipEventRecord(ev[0], st));
         hipLaunchKernelGGL(generic_kernel(plan), dim3(grid), dim3(256 * nt), plan->g_lds_bytes, st, ga);
-        if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[1], st));
+        if (ev) HIP_TRY(hipEventRecord(ev[1], st));
         HIP_TRY(hipGetLastError());
         return MFCC_OK;
     }
@@ -1223,31 +1262,26 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     fa.hop = plan->r.c.hop_length;
     fa.pad = plan->r.c.center ? plan->r.c.n_fft / 2 : 0;
     fa.reflect = plan->r.c.pad_mode == MFCC_PAD_REFLECT;
-    fa.ablate = std::getenv("MFCC_HIP_ABLATE") ? std::atoi(std::getenv("MFCC_HIP_ABLATE")) : 0;
     // all wavefronts of a workgroup draw the frames of one run from a counter in LDS: the CU
     // keeps one window of samples warm in L2 (measured 1.005 x the algorithmic HBM traffic, 1.9 x
     // with a private run per wavefront, MFCC_HIP_SHARE = 1) and its wavefronts finish together
-    fa.share = 16;
-    if (const char* e = std::getenv("MFCC_HIP_SHARE")) {
-        const int v = std::atoi(e);
-        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) fa.share = v;
-    }
+    fa.share = plan->share;
     fa.pw_mode = plan->r.c.power == 2.0f ? 0 : (plan->r.c.power == 1.0f ? 1 : 2);
     fa.half_power = 0.5f * plan->r.c.power;
     const FrontVariant& fv = pcm16 ? plan->front16 : plan->front;
     const int64_t wg_needed = (L.ub_tiles * TILE_FRAMES + fv.waves - 1) / fv.waves;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(wg_needed, plan->n_cu));
-    if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[0], st));
+    if (ev) HIP_TRY(hipEventRecord(ev[0], st));
     if (plan->fast_mode && mel_out && !spec_out) {
         FrontFn fn = fast_kernel(pcm16);
         hipLaunchKernelGGL(fn, dim3(grid), dim3(16 * 64), plan->fast_lds_bytes, st, fa);
-        if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[1], st));
+        if (ev) HIP_TRY(hipEventRecord(ev[1], st));
         HIP_TRY(hipGetLastError());
         return MFCC_OK;
     }
     hipLaunchKernelGGL(pcm16 ? fv.fn16 : fv.fn, dim3(grid), dim3(fv.waves * 64),
                        pcm16 ? plan->front16_lds_bytes : plan->front_lds_bytes, st, fa);
-    if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[1], st));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], st));
     (void)total_frames;
     HIP_TRY(hipGetLastError());
     return MFCC_OK;
@@ -1283,8 +1317,9 @@ static int execute_impl(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     char* ws = static_cast<char*>(d_workspace);
     float* mel = need_mel ? reinterpret_cast<float*>(ws + L.mel) : d_melspec_out;
 
+    const ProfSlot prof = take_prof_slot(plan);
     rc = launch_front(plan, d_pcm, pcm16, d_sample_offsets, d_frame_offsets, d_group, n_utts, total_frames,
-                      mel, nullptr, ws, L, st);
+                      mel, nullptr, ws, L, st, prof.ev);
     if (rc != MFCC_OK) return rc;
 
     DbDctArgs da;
@@ -1301,8 +1336,7 @@ static int execute_impl(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     if (da.vec_ok && da.n_mels <= 128 && da.n_mfcc <= 16) {
         // two workgroups (eight persistent wavefronts) per CU stream fastest: 0.121 ms per 10 h at
         // 128 mels against 0.131 with 4 to 16 per CU and 0.175 with one
-        static const int per_cu = std::getenv("MFCC_HIP_DB_GRID") ? std::max(1, std::atoi(std::getenv("MFCC_HIP_DB_GRID"))) : 2;
-        const int grid = std::max(1, std::min(blocks, plan->n_cu * per_cu));
+        const int grid = std::max(1, std::min(blocks, plan->n_cu * plan->db_per_cu));
         void (*fn)(const DbDctArgs) = nullptr;
         switch ((da.n_mels + 15) / 16) {
             case 1: fn = k_db_dct_small<1>; break;
@@ -1318,9 +1352,8 @@ static int execute_impl(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
     } else {
         hipLaunchKernelGGL(k_db_dct, dim3(blocks), dim3(256), 0, st, da);
     }
-    if (plan->profiling) HIP_TRY(hipEventRecord(plan->ev[2], st));
     HIP_TRY(hipGetLastError());
-    return MFCC_OK;
+    return finish_prof_slot(plan, prof, st);
 }
 
 int mfcc_execute(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sample_offsets,
@@ -1360,22 +1393,30 @@ int mfcc_execute_noalloc(const mfcc_plan* plan, const float* d_pcm, const int64_
 
 int mfcc_plan_set_profiling(mfcc_plan* plan, int enable) {
     if (!plan) return fail(MFCC_E_INVALID, "plan is NULL");
+    // (switching profiling on or off is for a quiet plan: no execute of it may be in flight on
+    // another thread; the executes themselves may then run concurrently)
     if (enable && !plan->ev_ring) {
+        plan->ev_done = new (std::nothrow) std::atomic<int64_t>[mfcc_plan::EV_RING];
         plan->ev_ring = new (std::nothrow) hipEvent_t[mfcc_plan::EV_RING][3]();
-        if (!plan->ev_ring) return fail(MFCC_E_NOMEM, "out of host memory");
+        if (!plan->ev_ring || !plan->ev_done) return fail(MFCC_E_NOMEM, "out of host memory");
         for (int i = 0; i < mfcc_plan::EV_RING; ++i)
             for (int j = 0; j < 3; ++j) HIP_TRY(hipEventCreate(&plan->ev_ring[i][j]));
     }
     plan->profiling = enable != 0;
-    plan->ev_count = 0;
-    plan->ev = nullptr;
+    plan->ev_count.store(0);
+    if (plan->ev_done)
+        for (int i = 0; i < mfcc_plan::EV_RING; ++i) plan->ev_done[i].store(0);
     return MFCC_OK;
 }
 
 int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_dct) {
     if (!plan || !plan->ev_ring) return fail(MFCC_E_INVALID, "profiling was not enabled on this plan");
-    if (plan->ev_count == 0) return fail(MFCC_E_INVALID, "no execute has been recorded since profiling was enabled");
-    hipEvent_t* ev = plan->ev_ring[(plan->ev_count - 1) % mfcc_plan::EV_RING];
+    const int64_t count = plan->ev_count.load();
+    if (count == 0) return fail(MFCC_E_INVALID, "no execute has been recorded since profiling was enabled");
+    const int slot = (int)((count - 1) % mfcc_plan::EV_RING);
+    if (plan->ev_done[slot].load(std::memory_order_acquire) != count)
+        return fail(MFCC_E_INVALID, "the last execute did not finish recording its events (it failed, or is still being issued)");
+    hipEvent_t* ev = plan->ev_ring[slot];
     HIP_TRY(hipEventSynchronize(ev[2]));
     if (ms_front) HIP_TRY(hipEventElapsedTime(ms_front, ev[0], ev[1]));
     if (ms_db_dct) HIP_TRY(hipEventElapsedTime(ms_db_dct, ev[1], ev[2]));
@@ -1385,15 +1426,21 @@ int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_
 int mfcc_plan_timing_history(const mfcc_plan* plan, int32_t max_n, float* ms_front, float* ms_db_dct) {
     if (!plan || !plan->ev_ring) return fail(MFCC_E_INVALID, "profiling was not enabled on this plan");
     if (max_n < 0) return fail(MFCC_E_INVALID, "max_n is negative");
-    const int64_t have = std::min<int64_t>(plan->ev_count, mfcc_plan::EV_RING);
+    const int64_t count = plan->ev_count.load();
+    const int64_t have = std::min<int64_t>(count, mfcc_plan::EV_RING);
     const int n = (int)std::min<int64_t>(have, max_n);
+    int got = 0;
     for (int i = 0; i < n; ++i) {
-        hipEvent_t* ev = plan->ev_ring[(plan->ev_count - n + i) % mfcc_plan::EV_RING];
+        const int64_t seq = count - n + i;
+        const int slot = (int)(seq % mfcc_plan::EV_RING);
+        if (plan->ev_done[slot].load(std::memory_order_acquire) != seq + 1) continue;   // a launch that failed
+        hipEvent_t* ev = plan->ev_ring[slot];
         HIP_TRY(hipEventSynchronize(ev[2]));
-        if (ms_front) HIP_TRY(hipEventElapsedTime(&ms_front[i], ev[0], ev[1]));
-        if (ms_db_dct) HIP_TRY(hipEventElapsedTime(&ms_db_dct[i], ev[1], ev[2]));
+        if (ms_front) HIP_TRY(hipEventElapsedTime(&ms_front[got], ev[0], ev[1]));
+        if (ms_db_dct) HIP_TRY(hipEventElapsedTime(&ms_db_dct[got], ev[1], ev[2]));
+        ++got;
     }
-    return n;
+    return got;
 }
 
 int mfcc_workspace_status(const void* d_workspace, void* stream) {
@@ -1435,10 +1482,11 @@ int mfcc_execute_spectrogram(const mfcc_plan* plan, const float* d_pcm,
         return fail(MFCC_E_WORKSPACE, "workspace too small: need " + std::to_string(L.total) + " bytes");
     if (reinterpret_cast<uintptr_t>(d_workspace) % 256)
         return fail(MFCC_E_INVALID, "workspace must be 256-byte aligned");
+    const ProfSlot prof = take_prof_slot(plan);
     rc = launch_front(plan, d_pcm, false, d_sample_offsets, d_frame_offsets, nullptr, n_utts, total_frames,
-                      nullptr, d_spec_out, static_cast<char*>(d_workspace), L, static_cast<hipStream_t>(stream));
-    if (rc == MFCC_OK && plan->profiling) HIP_TRY(hipEventRecord(plan->ev[2], static_cast<hipStream_t>(stream)));
-    return rc;
+                      nullptr, d_spec_out, static_cast<char*>(d_workspace), L, static_cast<hipStream_t>(stream), prof.ev);
+    if (rc != MFCC_OK) return rc;
+    return finish_prof_slot(plan, prof, static_cast<hipStream_t>(stream));
 }
 
 int mfcc_cmvn_accumulate(const float* d_feats, int64_t n_rows, int32_t n_mfcc, double* d_stats,

@@ -30,44 +30,7 @@ sys.path.insert(0, str(ROOT))
 import speech_to_text_amd as S  # noqa: E402
 from speech_to_text_amd.shard import lpt_shards, pack_batches  # noqa: E402
 
-SR = 16000
-SEED = 2024
-M64 = (1 << 64) - 1
-
-
-def _mix(x: torch.Tensor) -> torch.Tensor:
-    """splitmix64 finaliser on int64 tensors (wrapping arithmetic)."""
-    x = (x ^ (x >> 30).bitwise_and(0x3FFFFFFFF)) * -4658895280553007687       # 0xBF58476D1CE4E5B9
-    x = (x ^ (x >> 27).bitwise_and(0x1FFFFFFFFF)) * -7723592293110705685      # 0x94D049BB133111EB
-    return x ^ (x >> 31).bitwise_and(0x1FFFFFFFF)
-
-
-def generate_batch(utt_ids: np.ndarray, lens: np.ndarray, device) -> torch.Tensor:
-    """Speech-like audio on the int16 grid; sample s of utterance u depends on (SEED, u, s) only."""
-    so = np.zeros(len(lens) + 1, dtype=np.int64)
-    np.cumsum(lens, out=so[1:])
-    total = int(so[-1])
-    d_so = torch.from_numpy(so).to(device)
-    d_id = torch.from_numpy(utt_ids.astype(np.int64)).to(device)
-    pcm = torch.empty(total, dtype=torch.float32, device=device)
-    chunk = 1 << 26
-    for a in range(0, total, chunk):
-        b = min(total, a + chunk)
-        g = torch.arange(a, b, device=device, dtype=torch.int64)
-        u = torch.bucketize(g, d_so, right=True) - 1
-        s = g - d_so[u]
-        key = _mix(_mix(d_id[u] + SEED * 1000003) + s)
-        # two 24-bit uniforms -> one Gaussian (Box-Muller)
-        u1 = ((key >> 40).bitwise_and(0xFFFFFF).to(torch.float32) + 0.5) / 16777216.0
-        u2 = ((key >> 8).bitwise_and(0xFFFFFF).to(torch.float32) + 0.5) / 16777216.0
-        noise = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(6.283185307179586 * u2)
-        t = s.to(torch.float64) / SR
-        env = torch.sin(2 * np.pi * 1.5 * t).abs().float()
-        tone = torch.sin(2 * np.pi * 220.0 * t).float()
-        y = (0.1 * noise * env + 0.3 * tone).clamp_(-0.999, 0.999)
-        pcm[a:b] = torch.round(y * 32768.0) / 32768.0
-        del g, u, s, key, u1, u2, noise, t, env, tone, y
-    return pcm, so
+from bench import SR, corpus_lengths, generate_batch  # noqa: E402  (the corpus and its device-side generator)
 
 
 def main():
@@ -88,12 +51,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # the corpus: lengths U(2, 35) s until the target is reached; the same on every rank
-    rng = np.random.default_rng(SEED)
-    target = int(args.hours * 3600 * SR)
-    n_guess = int(target / (18.5 * SR) * 1.05) + 16
-    lens = (rng.uniform(2.0, 35.0, size=n_guess) * SR).astype(np.int64)
-    n_utts = int(np.searchsorted(np.cumsum(lens), target)) + 1
-    lens = lens[:n_utts]
+    lens = corpus_lengths(args.hours)
+    n_utts = len(lens)
     mine = lpt_shards(1 + lens // 512, world)[rank] if world > 1 else np.arange(n_utts)
     batches = pack_batches(lens[mine], int(args.batch_gb * 1e9 / 4))
 

@@ -56,6 +56,7 @@ for k, cs in vals.items():
             e["clock_GHz"] = mean["GRBM_GUI_ACTIVE"] / 8.0 / e["kernel_ns_under_profiler"]
     out["kernels"][k] = e
 dst = root / "profiles" / f"{tag}_sq_counters.json"
+(src / f"{tag}_sq_counters.json").write_text(json.dumps(out, indent=1))   # gpurun merges gpurun_out/ back, not profiles/
 dst.write_text(json.dumps(out, indent=1))
 for k, e in out["kernels"].items():
     print(k[:70])

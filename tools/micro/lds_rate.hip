@@ -1,6 +1,7 @@
 // LDS instruction cost on gfx950: cycles of the CU's LDS pipe per wave64 instruction, for reads
 // and writes of 4 / 8 / 16 bytes per lane, with all 64 lanes or only 16 lanes active, conflict-free
 // addresses.  16 wavefronts per CU issue back-to-back so that the pipe, not latency, is measured.
+// Cycles are SHADER clocks (s_memtime span of one workgroup), not wall time x a nominal frequency.
 //   hipcc -O3 --offload-arch=gfx950 tools/micro/lds_rate.hip -o tools/micro/lds_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -9,7 +10,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <int BYTES, bool WRITE, int ACTIVE>
-__global__ __launch_bounds__(1024) void k(float* out, int iters) {
+__global__ __launch_bounds__(1024) void k(float* out, int iters, long long* clk) {
+    const long long c0 = clock64(), w0 = wall_clock64();
     __shared__ __attribute__((aligned(16))) float lds[16 * 1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 16 * 1024; i += 1024) lds[i] = (float)i;
@@ -39,6 +41,8 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters) {
         }
     }
     if (acc.x + acc.y + acc.z == 12345.678f) out[0] = acc.x;
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 
 template <int BYTES, bool WRITE, int ACTIVE>
@@ -46,13 +50,18 @@ void run(float* d) {
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const int iters = 4000, blocks = prop.multiProcessorCount;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<BYTES, WRITE, ACTIVE>), dim3(blocks), dim3(1024), 0, 0, d, 10);
+    static long long* clk = nullptr;
+    if (!clk && hipMalloc(&clk, 16) != hipSuccess) return;
+    hipLaunchKernelGGL((k<BYTES, WRITE, ACTIVE>), dim3(blocks), dim3(1024), 0, 0, d, 10, clk);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<BYTES, WRITE, ACTIVE>), dim3(blocks), dim3(1024), 0, 0, d, iters);
+    hipLaunchKernelGGL((k<BYTES, WRITE, ACTIVE>), dim3(blocks), dim3(1024), 0, 0, d, iters, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double instr_per_cu = (double)iters * 8 * 16;
-    printf("%s %s%-3d %2d lanes: %.3f ms, %.2f cycles of the CU per instruction (at %.0f MHz)\n", WRITE ? "write" : "read ", BYTES == 9 || BYTES == 17 ? "2xb" : "b", (BYTES & ~1) * 8, ACTIVE, ms, ms * 1e-3 * prop.clockRate * 1e3 / instr_per_cu, prop.clockRate / 1e3);
+    long long h[2] = {0, 0};
+    if (hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost) != hipSuccess) return;
+    // shader-clock span of one workgroup (s_memtime) / instructions = SHADER cycles of the CU per instruction
+    printf("%s %s%-3d %2d lanes: %.3f ms, %.2f SHADER cycles of the CU per instruction (ran at %.0f MHz; %.2f at the nominal %.0f MHz)\n", WRITE ? "write" : "read ", BYTES == 9 || BYTES == 17 ? "2xb" : "b", (BYTES & ~1) * 8, ACTIVE, ms, (double)h[0] / instr_per_cu, h[1] > 0 ? 100.0 * h[0] / h[1] : 0.0, ms * 1e-3 * prop.clockRate * 1e3 / instr_per_cu, prop.clockRate / 1e3);
 }
 
 int main() {
