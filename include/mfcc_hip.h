@@ -155,7 +155,10 @@ int mfcc_execute_pcm16(const mfcc_plan* plan, const int16_t* d_pcm16, const int6
  * refused with MFCC_E_WORKSPACE (at the reference's settings about 130 000 frames, 1.1 hours of
  * 16 kHz audio).  The plan's device must be current.  All calls on one GPU share that GPU's array:
  * calls that overlap in time on one GPU (different streams or threads) race; calls on one stream,
- * or otherwise ordered, are safe -- every call initialises what it reads. */
+ * or otherwise ordered, are safe -- every call initialises what it reads.  The scratch is not
+ * exposed, so mfcc_workspace_status cannot be asked about it: a caller of this entry point vouches
+ * for d_group itself (NULL, or values in [0, n_utts); a value outside still cannot index out of
+ * bounds, its utterance just gets a maximum of its own). */
 #define MFCC_NOALLOC_SCRATCH_BYTES (64u * 1024u * 1024u)
 int mfcc_execute_noalloc(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sample_offsets,
                          const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,

@@ -195,8 +195,16 @@ def stft(y, *, n_fft=2048, hop_length=None, win_length=None, window="hann", cent
     """librosa.core.spectrum.stft (0.10.1): float64 window x input frames -> double-precision
     ``numpy.fft.rfft`` along the frame axis -> stored as complex64 for float32 input.
 
-    librosa 0.10 pads only the head/tail frames to avoid copying the signal; padding the whole
-    signal, as done here, is numerically identical.
+    Centred analysis follows 0.10's head / tail split literally: when the frames that touch the
+    left padding and those that touch the right padding are different frames, librosa pads two
+    SLICES of the signal (``y[:...]`` on the left only, ``y[tail_k * hop - n_fft // 2:]`` on the
+    right only) instead of the whole signal.  For ``pad_mode='constant'`` that is the same thing.
+    For ``'reflect'`` it is the same thing as long as the tail slice holds more than ``n_fft // 2``
+    samples.  A tail frame starts ``s`` samples after a multiple of the hop, and its slice holds
+    ``n_fft // 2 + (len(y) mod hop_length)`` samples: with ``hop_length >= n_fft / 2`` and a signal length
+    that is a multiple of the hop the slice is one sample short, numpy turns round inside it, and
+    the very last sample of the last frame is ``y[lo + 1]`` where a reflection of the whole signal
+    has ``y[lo - 1]`` (``lo`` = the slice's start).
     """
     if win_length is None:
         win_length = n_fft
@@ -215,31 +223,63 @@ def stft(y, *, n_fft=2048, hop_length=None, win_length=None, window="hann", cent
     fft_window = pad_center(fft_window, size=n_fft)
     fft_window = fft_window.reshape((-1, 1))                         # broadcast along frames
 
+    def frame(x):
+        """librosa.util.frame(x, frame_length=n_fft, hop_length=hop_length) -> (..., n_fft, F)."""
+        nf = 1 + (x.shape[-1] - n_fft) // hop_length if x.shape[-1] >= n_fft else 0
+        idx = np.arange(n_fft)[:, None] + hop_length * np.arange(nf)[None, :]
+        return x[..., idx]
+
+    y_frames_pre = y_frames_post = None
+    start = extra = 0
     if center:
         if n_fft > y.shape[-1]:
             warnings.warn(f"n_fft={n_fft} is too large for input signal of length={y.shape[-1]}",
                           stacklevel=2)
         padding = [(0, 0)] * y.ndim
-        padding[-1] = (n_fft // 2, n_fft // 2)
-        y = np.pad(y, padding, mode=pad_mode)
+        start_k = int(np.ceil(n_fft // 2 / hop_length))                     # frames that touch the left padding
+        tail_k = (y.shape[-1] + n_fft // 2 - n_fft) // hop_length + 1      # first frame that touches the right padding
+        if tail_k <= start_k:
+            # head and tail overlap: pad the whole signal
+            padding[-1] = (n_fft // 2, n_fft // 2)
+            y = np.pad(y, padding, mode=pad_mode)
+        else:
+            start = start_k * hop_length - n_fft // 2           # the middle of the signal starts here
+            padding[-1] = (n_fft // 2, 0)
+            y_pre = np.pad(y[..., : (start_k - 1) * hop_length - n_fft // 2 + n_fft + 1], padding, mode=pad_mode)
+            y_frames_pre = frame(y_pre)[..., :start_k]
+            extra = y_frames_pre.shape[-1]
+            if tail_k * hop_length - n_fft // 2 + n_fft <= y.shape[-1] + n_fft // 2:
+                padding[-1] = (0, n_fft // 2)
+                y_post = np.pad(y[..., tail_k * hop_length - n_fft // 2:], padding, mode=pad_mode)
+                y_frames_post = frame(y_post)
+                extra += y_frames_post.shape[-1]
+            else:
+                y_frames_post = y_frames_pre[..., :0]
     elif n_fft > y.shape[-1]:
         raise ParameterError(f"n_fft={n_fft} is too large for uncentered analysis of input "
                              f"signal of length={y.shape[-1]}")
 
-    F = 1 + (y.shape[-1] - n_fft) // hop_length
-    # librosa.util.frame(y, frame_length=n_fft, hop_length=hop_length) -> (..., n_fft, F)
-    idx = np.arange(n_fft)[:, None] + hop_length * np.arange(F)[None, :]
+    y_frames = frame(y[..., start:])                                # (..., n_fft, middle frames), y's dtype
     if dtype is None:
         dtype = _dtype_r2c(y.dtype)
-    shape = list(y.shape[:-1]) + [1 + n_fft // 2, F]
+    shape = list(y_frames.shape)
+    shape[-2] = 1 + n_fft // 2
+    shape[-1] += extra
     stft_matrix = np.zeros(shape, dtype=dtype, order="F")
 
-    n_columns = max(1, int(MAX_MEM_BLOCK // (np.prod(shape[:-1]) * stft_matrix.itemsize)))
-    for bl_s in range(0, F, n_columns):
-        bl_t = min(bl_s + n_columns, F)
-        frames = y[..., idx[:, bl_s:bl_t]]                          # (..., n_fft, cols), y dtype
+    off_start = 0
+    if center and extra > 0:
+        off_start = y_frames_pre.shape[-1]
+        stft_matrix[..., :off_start] = np.fft.rfft(fft_window * y_frames_pre, axis=-2)
+        off_end = y_frames_post.shape[-1]
+        if off_end > 0:
+            stft_matrix[..., -off_end:] = np.fft.rfft(fft_window * y_frames_post, axis=-2)
+
+    n_columns = max(1, int(MAX_MEM_BLOCK // (np.prod(y_frames.shape[:-1]) * y_frames.itemsize)))
+    for bl_s in range(0, y_frames.shape[-1], n_columns):
+        bl_t = min(bl_s + n_columns, y_frames.shape[-1])
         # float64 window * float32 frames -> float64 product -> double-precision rFFT
-        stft_matrix[..., bl_s:bl_t] = np.fft.rfft(fft_window * frames, axis=-2)
+        stft_matrix[..., bl_s + off_start:bl_t + off_start] = np.fft.rfft(fft_window * y_frames[..., bl_s:bl_t], axis=-2)
     return stft_matrix
 
 

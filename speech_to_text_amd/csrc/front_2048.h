@@ -183,12 +183,30 @@ __device__ __forceinline__ float apply_power(float mag2, int pw_mode, float half
     return pw_mode == 1 ? sqrtf(mag2) : powf(mag2, half_power);
 }
 
-__device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t T) {
-    if (T <= 1) return 0;
-    const int64_t period = 2 * (T - 1);
-    int64_t m = i % period;
+// numpy's 'reflect' extension of the samples lo .. T-1 (the edge sample is not repeated; a pad
+// longer than the slice reflects back and forth inside it), as an index into the utterance.
+__device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t T, int64_t lo = 0) {
+    const int64_t L = T - lo;
+    if (L <= 1) return lo;
+    const int64_t period = 2 * (L - 1);
+    int64_t m = (i - lo) % period;
     if (m < 0) m += period;
-    return m < T ? m : period - m;
+    return lo + (m < L ? m : period - m);
+}
+
+// librosa 0.10's stft pads the frames that reach past the end of the signal from the SLICE
+// y[tail_k hop - n_fft/2 :] (right side only) whenever those frames are not also frames that touch
+// the left padding; the left side and the overlapping case pad from the signal's start.  Returns
+// the first sample of the slice the frame starting at `start` (= t hop - n_fft/2) reflects in: 0
+// unless it is such a tail frame.  Only for hop >= n_fft/2 can the slice be shorter than the
+// padding, and only then does this differ from reflecting the whole signal.
+__device__ __forceinline__ int reflect_slice_start(int start, int T, int hop, int n_fft) {
+    const int half = n_fft / 2;
+    const int start_k = (half + hop - 1) / hop;           // frames that touch the left padding
+    const int tail_k = (T + half - n_fft) / hop + 1;       // first frame that touches the right padding
+    if (tail_k <= start_k) return 0;                       // (also whenever T + half < n_fft)
+    const int lo = tail_k * hop - half;
+    return start >= lo ? lo : 0;
 }
 
 // Wave-uniform read of a tile descriptor through the scalar cache (tiles are written by an
@@ -220,13 +238,14 @@ __device__ __forceinline__ float load_sample(const void* base, int64_t idx, bool
 
 // `p`: first sample of the utterance.
 __device__ __noinline__ void stage_edge_frame(float* X, const void* pcm, int64_t soff, bool pcm16, int start,
-                                              int T, int reflect, int lane) {
+                                              int T, int reflect, int lane, int hop) {
+    const int lo = reflect ? reflect_slice_start(start, T, hop, NFFT) : 0;
 #pragma unroll 1
     for (int n2 = 0; n2 < 32; ++n2) {
         const int idx = start + lane + 64 * n2;
         float v = 0.0f;
         if (reflect) {
-            if (T > 0) v = load_sample(pcm, soff + reflect_index(idx, T), pcm16);
+            if (T > 0) v = load_sample(pcm, soff + reflect_index(idx, T, lo), pcm16);
         } else if (idx >= 0 && idx < T) {
             v = load_sample(pcm, soff + idx, pcm16);
         }
@@ -464,7 +483,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048(const FrontArgs a) 
             const int16_t* pp16 = static_cast<const int16_t*>(a.pcm) + s0;
             if (!interior) {
                 // edge frames (overlapping the padding) come through LDS
-                stage_edge_frame(X, a.pcm, tc.soff, PCM16, t * a.hop - a.pad, tc.T, a.reflect, lane);
+                stage_edge_frame(X, a.pcm, tc.soff, PCM16, t * a.hop - a.pad, tc.T, a.reflect && a.pad, lane, a.hop);
 #pragma unroll
                 for (int n2 = 0; n2 < 32; ++n2) src[n2] = X[lane + 64 * n2];
                 // leave nothing of the staged samples behind: the padding of the power-spectrum

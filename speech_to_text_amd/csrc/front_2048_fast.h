@@ -197,7 +197,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
         if (interior) {
             load_samples(tc.soff, t);
         } else {
-            stage_edge_frame(X, a.pcm, tc.soff, PCM16, t * a.hop - a.pad, tc.T, a.reflect, lane);
+            stage_edge_frame(X, a.pcm, tc.soff, PCM16, t * a.hop - a.pad, tc.T, a.reflect && a.pad, lane, a.hop);
 #pragma unroll
             for (int n2 = 0; n2 < 32; ++n2) smp[n2] = X[lane + 64 * n2];
 #pragma unroll 1

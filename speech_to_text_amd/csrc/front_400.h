@@ -187,7 +187,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_16a(const Pow2Args a) {
             for (int i = 0; i < NA; ++i) x[i] = 0.0f;
 #pragma unroll 1
             for (int t = 0; t < nvalid; ++t) {
-                kp2::stage_edge_rows(X, a.pcm, tc.soff, PCM16, first + t * a.hop, tc.T, a.reflect, lane, (N + 63) / 64);
+                kp2::stage_edge_rows(X, a.pcm, tc.soff, PCM16, first + t * a.hop, tc.T, a.reflect && a.pad, lane, (N + 63) / 64, a.hop, N);
                 if (tf == t) {
 #pragma unroll
                     for (int i = 0; i < NA; ++i) x[i] = X[16 * i + b];

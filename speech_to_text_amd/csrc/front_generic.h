@@ -106,12 +106,13 @@ __global__ __launch_bounds__(256 * NT) void k_melspec_generic(const GenArgs a) {
         for (int fi = 0; fi < 4; ++fi) {
             const int f = 4 * wq + fi;
             const int start = (ti.f0 + f) * a.hop - a.pad;
+            const int lo = (a.reflect && a.pad) ? reflect_slice_start(start, ti.T, a.hop, a.n_fft) : 0;
             for (int n = lane; n < a.kpad; n += 64) {
                 float v = 0.0f;
                 if (f < nvalid && n < a.n_fft) {
                     const int idx = start + n;
                     if (a.reflect) {
-                        if (ti.T > 0) v = load_sample(a.pcm, ti.soff + reflect_index(idx, ti.T), pcm16);
+                        if (ti.T > 0) v = load_sample(a.pcm, ti.soff + reflect_index(idx, ti.T, lo), pcm16);
                     } else if (idx >= 0 && idx < ti.T) {
                         v = load_sample(a.pcm, ti.soff + idx, pcm16);
                     }

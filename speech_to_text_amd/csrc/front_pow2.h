@@ -78,14 +78,17 @@ constexpr size_t lds_bytes(int region, int waves, int fpr, int mel_quads, int me
                             2 * 64 * (size_t)mel_rounds + 4 /* unit counter */);
 }
 
+// hop, n_fft: of the transform (for the slice librosa reflects a tail frame in; `start` is the
+// frame's first sample, t hop - n_fft / 2)
 __device__ __noinline__ void stage_edge_rows(float* X, const void* pcm, int64_t soff, bool pcm16, int start, int T,
-                                             int reflect, int lane, int rows) {
+                                             int reflect, int lane, int rows, int hop, int n_fft) {
+    const int lo = reflect ? k2048::reflect_slice_start(start, T, hop, n_fft) : 0;
 #pragma unroll 1
     for (int n2 = 0; n2 < rows; ++n2) {
         const int idx = start + lane + 64 * n2;
         float v = 0.0f;
         if (reflect) {
-            if (T > 0) v = k2048::load_sample(pcm, soff + k2048::reflect_index(idx, T), pcm16);
+            if (T > 0) v = k2048::load_sample(pcm, soff + k2048::reflect_index(idx, T, lo), pcm16);
         } else if (idx >= 0 && idx < T) {
             v = k2048::load_sample(pcm, soff + idx, pcm16);
         }
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_pow2(const Pow2Args a) {
                 }
             } else {
                 // edge frames (overlapping the padding or the utterance's end) come through LDS
-                kp2::stage_edge_rows(X, a.pcm, tc.soff, PCM16, start, tc.T, a.reflect, lane, ROWS);
+                kp2::stage_edge_rows(X, a.pcm, tc.soff, PCM16, start, tc.T, a.reflect && a.pad, lane, ROWS, a.hop, N);
 #pragma unroll
                 for (int j = 0; j < ROWS; ++j) rt[j] = X[lane + 64 * j];
             }

@@ -11,6 +11,10 @@
 #include <string>
 #include <vector>
 
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
+
 #include "../../include/mfcc_hip.h"
 
 namespace {
@@ -199,11 +203,29 @@ int mfcc_host_write_feature_file(const char* path, const char* dataset_name, con
         return MFCC_E_INVALID;
     }
 
-    // Written under a temporary name and renamed once complete: a reader that walks the directory
-    // (/root/reference/src/trainer.py:106-114) never sees a truncated feature file, whatever
-    // interrupts the writer.
-    const std::string tmp = std::string(path) + ".tmp";
+    // Written under a temporary name and renamed once complete.  The reference's reader opens every
+    // file it finds under the feature directory, whatever its name
+    // (/root/reference/src/trainer.py:106-110), so the temporary lives OUTSIDE that directory: in a
+    // sibling "<directory>.partial" on the same file system (rename stays atomic).  A killed writer
+    // leaves its half-written file there, where no reader walks.  A path without a directory part
+    // has no sibling to use and takes "<path>.tmp".
+    const std::string full(path);
+    const size_t slash = full.find_last_of('/');
+    std::string tmp, side;
+    if (slash == std::string::npos || slash == 0) {
+        tmp = full + ".tmp";
+    } else {
+        std::string dir = full.substr(0, slash);
+        while (dir.size() > 1 && dir.back() == '/') dir.pop_back();
+        side = dir + ".partial";
+        (void)::mkdir(side.c_str(), 0777);
+        tmp = side + "/" + full.substr(slash + 1) + "." + std::to_string((long)::getpid());
+    }
     FILE* fp = std::fopen(tmp.c_str(), "wb");
+    if (!fp && !side.empty()) {          // another writer removed the (then empty) side directory meanwhile
+        (void)::mkdir(side.c_str(), 0777);
+        fp = std::fopen(tmp.c_str(), "wb");
+    }
     if (!fp) {
         g_file_err = std::string("cannot open ") + tmp;
         return MFCC_E_INVALID;
@@ -239,6 +261,15 @@ int mfcc_host_write_feature_files(int32_t n_files, const char* const* paths, con
                                                     attr_is_string, attr_ints + (size_t)i * n_attrs,
                                                     attr_strings + (size_t)i * n_attrs);
         if (rc != MFCC_OK) return rc;
+    }
+    if (n_files > 0) {      // the side directory of the temporaries, if this batch left it empty
+        const std::string full(paths[0]);
+        const size_t slash = full.find_last_of('/');
+        if (slash != std::string::npos && slash > 0) {
+            std::string dir = full.substr(0, slash);
+            while (dir.size() > 1 && dir.back() == '/') dir.pop_back();
+            (void)::rmdir((dir + ".partial").c_str());
+        }
     }
     return MFCC_OK;
 }

@@ -1542,7 +1542,11 @@ int mfcc_dct(const mfcc_plan* plan, const float* d_logmel, int64_t rows, float* 
     if (rows == 0) return MFCC_OK;
     if (!d_logmel || !d_out) return fail(MFCC_E_INVALID, "NULL buffer");
     if (rows > 0x7fffffffLL * 16) return fail(MFCC_E_UNSUPPORTED, "batch too large: split it");
-    HIP_TRY(hipSetDevice(plan->device));
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));      // like every entry point: the caller's current device is left alone
+    if (dev != plan->device)
+        return fail(MFCC_E_INVALID, "the plan was made on device " + std::to_string(plan->device) +
+                                        " but the current device is " + std::to_string(dev));
     const int64_t tiles = (rows + TILE_FRAMES - 1) / TILE_FRAMES;
     hipLaunchKernelGGL(k_dct_rows, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        d_logmel, rows, plan->d_dct_frag, plan->d_lifter, d_out, plan->r.c.n_mels, plan->n_mels_pad,

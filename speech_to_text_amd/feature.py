@@ -314,13 +314,23 @@ def mfcc(*, y=None, sr=22050, S=None, n_mfcc=20, dct_type=2, norm="ortho", lifte
 
 
 def _mfcc_of_logmel(S, sr, n_mfcc, dct_type, norm, lifter, device) -> np.ndarray:
-    """``scipy.fftpack.dct(S, axis=-2, type, norm)[..., :n_mfcc, :]`` and the lifter, on the GPU."""
+    """``scipy.fftpack.dct(S, axis=-2, type, norm)[..., :n_mfcc, :]`` and the lifter, on the GPU.
+    As in librosa, asking for more coefficients than S has bands returns one row per band.  The
+    result is float32 whatever the dtype of S (librosa keeps a float64 S in float64).  Only the
+    DCT and lifter tables of the plan are used; its front end is the cheapest one to build (a
+    256-point transform), whose tables never see data here."""
     S = np.asarray(S)
     if S.ndim < 2:
         raise ParameterError("S must have shape (..., n_mels, n_frames)")
     n_mels, F = int(S.shape[-2]), int(S.shape[-1])
     lead = tuple(S.shape[:-2])
-    config = make_config(sr=sr, n_mfcc=n_mfcc, dct_type=dct_type, norm=norm, lifter=lifter, n_mels=n_mels)
+    if lifter < 0:
+        raise ParameterError("MFCC lifter must be a non-negative number")
+    n_mfcc = min(int(n_mfcc), n_mels)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # empty-filter warnings of a filterbank nobody uses
+        config = make_config(sr=sr, n_mfcc=n_mfcc, dct_type=dct_type, norm=norm, lifter=lifter, n_mels=n_mels,
+                             n_fft=256, hop_length=64)
     plan = get_plan(config, _device(device))
     rows = int(np.prod(lead, dtype=np.int64)) * F
     x = torch.from_numpy(np.ascontiguousarray(np.swapaxes(S, -1, -2), dtype=np.float32)).to(plan.device)

@@ -214,26 +214,53 @@ def write_datasets(path, datasets) -> None:
         snod += struct.pack("<QQI4x16x", off, ad, 0)
     snod += b"\x00" * (SNOD - len(snod))
 
-    # written under a temporary name and renamed when complete: a directory walk never meets a
-    # truncated file
-    tmp = str(path) + ".tmp"
-    with open(tmp, "wb") as f:
-        for part in (sb, root, btree, heap, heap_data, snod):
-            f.write(part)
-        for d, ad, (hdr, data_at, heap_at) in zip(prepared, a_data, headers):
-            struct.pack_into("<Q", hdr, data_at, ad if d["nbytes"] else UNDEF)
-            for at, c in heap_at:
-                struct.pack_into("<Q", hdr, at, gaddr[c])
-            f.write(hdr)
-        for c in range(len(gaddr)):
-            f.write(strings.encode(c))
-        for d in prepared:
-            if d["kind"] == "str":
-                raw = b"".join(struct.pack("<IQI", ln, gaddr[c], idx) for c, idx, ln in d["refs"])
-            else:
-                raw = d["arr"].tobytes()
-            f.write(raw + b"\x00" * (-len(raw) % 8))
-    os.replace(tmp, path)
+    # Written under a temporary name and renamed when complete.  The reference's reader opens every
+    # file under the feature directory (/root/reference/src/trainer.py:106-110), so the temporary
+    # lives in a sibling "<directory>.partial" on the same file system, where no reader walks; it is
+    # removed if the write fails.
+    tmp, side = _staging_path(path)
+    try:
+        with open(tmp, "wb") as f:
+            for part in (sb, root, btree, heap, heap_data, snod):
+                f.write(part)
+            for d, ad, (hdr, data_at, heap_at) in zip(prepared, a_data, headers):
+                struct.pack_into("<Q", hdr, data_at, ad if d["nbytes"] else UNDEF)
+                for at, c in heap_at:
+                    struct.pack_into("<Q", hdr, at, gaddr[c])
+                f.write(hdr)
+            for c in range(len(gaddr)):
+                f.write(strings.encode(c))
+            for d in prepared:
+                if d["kind"] == "str":
+                    raw = b"".join(struct.pack("<IQI", ln, gaddr[c], idx) for c, idx, ln in d["refs"])
+                else:
+                    raw = d["arr"].tobytes()
+                f.write(raw + b"\x00" * (-len(raw) % 8))
+        os.replace(tmp, path)
+    except BaseException:
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        raise
+    finally:
+        if side is not None:
+            try:
+                os.rmdir(side)          # only when this writer left it empty
+            except OSError:
+                pass
+
+
+def _staging_path(path):
+    """(temporary file, side directory or None) for a file that will be renamed to ``path``."""
+    path = os.fspath(path)
+    d, base = os.path.split(path)
+    d = d.rstrip("/") if len(d) > 1 else d
+    if d in ("", "/"):
+        return path + ".tmp", None
+    side = d + ".partial"
+    os.makedirs(side, exist_ok=True)
+    return os.path.join(side, f"{base}.{os.getpid()}"), side
 
 
 def write_features_native(path, data: np.ndarray, attrs: Dict[str, AttrValue], name: str = "mfccs") -> None:

@@ -108,12 +108,15 @@ class DecodeAhead:
             res = [self._fetch(i) for i in idx]
             sizes = [int(self._size_of(r)) for r in res]
             with self._cv:
+                # The result is queued BEFORE the chunk stops counting as in flight: the feeder
+                # queues its end marker once nothing is in flight, and a result queued after that
+                # marker would be lost.
+                self._out.put((idx, res, sizes))
                 self._inflight -= 1
                 self._ahead += sum(sizes)
                 self.peak_ahead = max(self.peak_ahead, self._ahead)
                 self.n_fetched += len(idx)
                 self._cv.notify_all()
-            self._out.put((idx, res, sizes))
         except BaseException as e:                       # a worker's exception reaches the consumer,
             with self._cv:                               # as it does from Pool.imap_unordered
                 self._inflight -= 1

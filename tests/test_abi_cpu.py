@@ -149,3 +149,18 @@ def test_no_cpu_fallback_without_gpu():
 
     with pytest.raises(RuntimeError):
         S.mfcc(y=np.zeros(4096, np.float32))
+
+
+def test_odd_n_fft_is_unsupported_not_invalid():
+    """librosa computes an odd-length transform; the library has no kernel for one and says so
+    with MFCC_E_UNSUPPORTED (a limit of the library) rather than MFCC_E_INVALID, which the Python
+    layer turns into librosa's ParameterError.  Decided before any device is touched."""
+    lib = _lib.lib()
+    for n_fft in (401, 2047, 3):
+        c = _lib.MfccConfigC()
+        lib.mfcc_config_default(C.byref(c))
+        c.n_fft = n_fft
+        handle = C.c_void_p()
+        rc = lib.mfcc_plan_create(C.byref(c), C.byref(handle))
+        assert rc == _lib.MFCC_E_UNSUPPORTED and not handle.value
+        assert "odd n_fft" in _lib.last_error()

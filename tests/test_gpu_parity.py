@@ -17,6 +17,9 @@ pytestmark = pytest.mark.gpu
 DB_TOL = 1e-2          # dB, absolute, on log-mel / MFCC
 MEL_RTOL = 1e-4        # relative, on mel power
 MEL_FLOOR = 2e-7       # x max mel power of the utterance
+MEL_FLOOR_MAX_FRACTION = 1e-3     # of an utterance's mel values may exceed the relative bound alone ...
+MEL_FLOOR_MIN_DEPTH_DB = 60.0     # ... and only bands at least this far below its largest band
+FLOOR_USE = []                    # (elements that needed the floor, elements, highest level in dB re peak) per call
 
 
 def check_mel(got, want, amin=1e-10, top_db=80.0):
@@ -27,7 +30,8 @@ def check_mel(got, want, amin=1e-10, top_db=80.0):
         within top_db of the utterance's largest band, 10 log10 of the two values differ by
         <= 1e-2 dB -- so the floor of (1) never hides an error that would survive into the
         features.
-    Prints how many elements needed the floor and how far below the peak the highest of them sits."""
+    The floor's use is bounded too: at most MEL_FLOOR_MAX_FRACTION of the elements may need it,
+    and none that sits less than MEL_FLOOR_MIN_DEPTH_DB below the utterance's largest band."""
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     peak = np.abs(want).max()
@@ -37,8 +41,11 @@ def check_mel(got, want, amin=1e-10, top_db=80.0):
     need_floor = err > MEL_RTOL * np.abs(want)
     if need_floor.any() and peak > 0:
         level = 10.0 * np.log10(np.maximum(want[need_floor], 1e-300) / peak)
-        print(f"check_mel: {int(need_floor.sum())} of {want.size} elements ({need_floor.mean():.2%}) exceed the "
-              f"relative bound alone; the highest sits {level.max():.1f} dB below the peak")
+        FLOOR_USE.append((int(need_floor.sum()), int(want.size), float(level.max())))
+        assert need_floor.mean() <= MEL_FLOOR_MAX_FRACTION, \
+            f"{need_floor.mean():.2%} of the mel values need the absolute floor"
+        assert level.max() <= -MEL_FLOOR_MIN_DEPTH_DB, \
+            f"a band only {-level.max():.1f} dB below the peak needs the absolute floor"
     db_got = 10.0 * np.log10(np.maximum(amin, got))
     db_want = 10.0 * np.log10(np.maximum(amin, want))
     kept = db_want >= db_want.max() - top_db
@@ -459,3 +466,101 @@ def test_mfcc_of_a_given_log_mel_spectrogram(S, shape, dct_type, norm, lifter):
         full = S.mfcc(y=y, n_mfcc=13)
         via = S.mfcc(S=R.power_to_db(R.melspectrogram(y=y)), n_mfcc=13)
         np.testing.assert_allclose(via, full, atol=DB_TOL)
+    # more coefficients asked for than there are bands: one row per band, as scipy's slice gives
+    if dct_type == 2 and lifter == 0:
+        many = S.mfcc(S=logmel, n_mfcc=shape[-2] + 7, dct_type=dct_type, norm=norm)
+        want_many = R.mfcc(S=logmel.astype(np.float64), n_mfcc=shape[-2] + 7, dct_type=dct_type, norm=norm)
+        assert many.shape == want_many.shape == shape
+        np.testing.assert_allclose(many, want_many, rtol=2e-5, atol=2e-5 * np.abs(want_many).max())
+
+
+# What fp32 transforms can promise on utterances shorter than one frame under reflect padding: a
+# few samples repeated many times give a line spectrum, and the bands between the lines hold only
+# window side lobes 50-80 dB below the peak -- where an fp32 transform's error, which is relative
+# to the frame's energy, is a visible fraction of the band.  The bounds below are asserted, not
+# assumed: log-mel inside top_db of the utterance's peak, and the features themselves.
+SHORT_REFLECT_LOGMEL_TOL = 1e-2      # dB, bands within top_db (80 dB) of the peak
+SHORT_REFLECT_LOGMEL_55_TOL = 1e-3   # dB, bands within 55 dB of the peak
+SHORT_REFLECT_MFCC_TOL = 1e-2        # dB, the features (orthonormal DCT, no lifter)
+
+
+def test_short_utterances_reflect_padding(S):
+    """Utterances shorter than n_fft with pad_mode='reflect' (librosa only warns), over every
+    front-end kernel and the rarely used parameters, against the oracle: 240 seeded cases."""
+    import warnings
+
+    rng = np.random.default_rng(20241112)
+    worst_mel = worst_mel55 = worst_mfcc = 0.0
+    where = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for case in range(240):
+            n_fft = int(rng.choice([2048, 2048, 2048, 1024, 960, 800, 640, 600, 512, 480, 400, 320, 256]))
+            kw = dict(n_fft=n_fft, hop_length=int(rng.integers(n_fft // 8, n_fft + 1)),
+                      n_mels=int(rng.choice([20, 40, 64, 80, 128])), sr=int(rng.choice([8000, 16000, 22050])),
+                      pad_mode="reflect")
+            if rng.random() < 0.3:
+                kw["win_length"] = int(rng.integers(n_fft // 2, n_fft + 1))
+            if rng.random() < 0.2:
+                kw["power"] = float(rng.choice([1.0, 3.0]))
+            if rng.random() < 0.2:
+                kw["htk"] = True
+            if rng.random() < 0.15:
+                kw["window"] = str(rng.choice(["hamming", "blackman"]))
+            L = int(rng.integers(2, n_fft))
+            kind = int(rng.integers(0, 3))
+            scale = float(rng.choice([1e-3, 0.1, 1.0]))
+            if kind == 0:
+                y = (rng.standard_normal(L) * scale).astype(np.float32)
+            elif kind == 1:
+                y = (scale * np.sin(2 * np.pi * rng.uniform(50, 3000) * np.arange(L) / 16000.0)).astype(np.float32)
+            else:
+                y = (scale * speech_like(L, seed=case)).astype(np.float32)
+            want = R.melspectrogram(y=y, **kw).astype(np.float64)
+            got = S.melspectrogram(y=y, **kw).astype(np.float64)
+            assert got.shape == want.shape
+            dbw = 10.0 * np.log10(np.maximum(1e-10, want))
+            dbg = 10.0 * np.log10(np.maximum(1e-10, got))
+            d = np.abs(dbw - dbg)
+            e80 = float(d[dbw >= dbw.max() - 80.0].max())
+            e55 = float(d[dbw >= dbw.max() - 55.0].max())
+            f_want = R.mfcc(y=y, n_mfcc=13, **kw)
+            f_got = S.mfcc(y=y, n_mfcc=13, **kw)
+            ef = float(np.abs(f_want - f_got).max())
+            if e80 > worst_mel:
+                where = dict(kw, L=L, kind=kind, scale=scale)
+            worst_mel, worst_mel55, worst_mfcc = max(worst_mel, e80), max(worst_mel55, e55), max(worst_mfcc, ef)
+    print(f"short/reflect: worst log-mel diff {worst_mel:.2e} dB inside top_db, {worst_mel55:.2e} dB within 55 dB of the "
+          f"peak, worst MFCC diff {worst_mfcc:.2e} dB; worst case {where}")
+    assert worst_mel <= SHORT_REFLECT_LOGMEL_TOL
+    assert worst_mel55 <= SHORT_REFLECT_LOGMEL_55_TOL
+    assert worst_mfcc <= SHORT_REFLECT_MFCC_TOL
+
+
+@pytest.mark.parametrize("n_fft,hop,around", [(2048, 1024, 9000), (2048, 1500, 20000), (512, 400, 1990), (1024, 1000, 7000),
+                                              (480, 240, 3000), (960, 480, 5000), (600, 310, 4000), (256, 250, 1130)])
+def test_reflect_padding_of_tail_frames_follows_librosa_slices(S, n_fft, hop, around):
+    """hop >= n_fft / 2 with pad_mode='reflect' and a signal length that is a multiple of the hop:
+    librosa 0.10 pads the last frame from a slice of exactly n_fft/2 samples, one fewer than numpy
+    needs to reflect n_fft/2 samples without turning round, so the frame's last sample is
+    y[lo + 1] rather than y[lo - 1].  Every front-end kernel indexes the same way: with a loud
+    sample at lo - 1 (which a reflection of the whole signal would fold into the frame) the |STFT|
+    tap still equals the oracle's to fp32 accuracy."""
+    from tests.test_oracle_known_answers import _short_tail_length
+
+    T = _short_tail_length(n_fft, hop, around)
+    half = n_fft // 2
+    lo = ((T + half - n_fft) // hop + 1) * hop - half           # the slice the last frame is padded from: y[lo:]
+    assert T - lo == half
+    y = (1e-3 * np.random.default_rng(n_fft + hop).standard_normal(T)).astype(np.float32)
+    y[lo - 1] = 0.9
+    want = np.abs(R.stft(y, n_fft=n_fft, hop_length=hop, pad_mode="reflect")).astype(np.float64)
+    got = S.spectrogram(y=y, n_fft=n_fft, hop_length=hop, pad_mode="reflect", power=1.0).astype(np.float64)
+    assert got.shape == want.shape
+    assert np.abs(got[:, -1] - want[:, -1]).max() / want[:, -1].max() < 1e-5
+    assert np.abs(got - want).max() / want.max() < 1e-5
+    sr = 16000 if n_fft < 2048 else 22050
+    n_mels = 40 if n_fft < 2048 else 128
+    np.testing.assert_allclose(S.mfcc(y=y, n_fft=n_fft, hop_length=hop, pad_mode="reflect", n_mfcc=13, sr=sr, n_mels=n_mels),
+                               R.mfcc(y=y, n_fft=n_fft, hop_length=hop, pad_mode="reflect", n_mfcc=13, sr=sr, n_mels=n_mels),
+                               rtol=0, atol=DB_TOL)

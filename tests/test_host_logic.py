@@ -347,3 +347,26 @@ def test_feature_dataset_streams_its_source():
     for i in (0, 5, 11):
         want = R.process_audio_features(speech_like(int(ds.lens[i]), seed=1000 + i))
         assert np.array_equal(fd[i][0], want) and fd[i][1:] == [16000, f"TEXT {i}", 3 + i]
+
+
+def test_decode_ahead_never_loses_the_last_chunk(monkeypatch):
+    """The end marker must not overtake a result: every worker's hand-over to the output queue is
+    delayed (so the last chunk's put is still pending when nothing looks in flight any more, if
+    the two were ordered wrongly) and every index must still come out, exactly once."""
+    import queue
+    import time
+
+    from speech_to_text_amd.ingest import DecodeAhead
+
+    real_put = queue.Queue.put
+
+    def slow_put(self, item, *a, **kw):
+        if isinstance(item, tuple):          # a worker's result (the end marker is a bare object)
+            time.sleep(0.02)
+        return real_put(self, item, *a, **kw)
+
+    monkeypatch.setattr(queue.Queue, "put", slow_put)
+    for n, workers, chunk in [(37, 8, 8), (5, 3, 2), (1, 4, 8), (64, 8, 3)]:
+        da = DecodeAhead(lambda i: np.full(3, i), range(n), size_of=len, workers=workers, chunk=chunk)
+        seen = sorted(i for i, r in da if int(r[0]) == i)
+        assert seen == list(range(n)), (n, workers, chunk, seen)

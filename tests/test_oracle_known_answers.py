@@ -173,3 +173,81 @@ def test_stft_rejects_the_pad_modes_librosa_rejects(pad_mode):
 
     with pytest.raises(ParameterError):
         make_config(n_fft=2048, hop_length=512, pad_mode=pad_mode).validate()
+
+
+def _stft_whole_signal_padding(y, n_fft, hop, pad_mode):
+    """Independent statement of a centred STFT that pads the WHOLE signal (what librosa < 0.10 did)."""
+    win = R.pad_center(R.get_window("hann", n_fft, fftbins=True), size=n_fft).reshape(-1, 1)
+    yp = np.pad(y, (n_fft // 2, n_fft // 2), mode=pad_mode)
+    F = 1 + (len(yp) - n_fft) // hop
+    idx = np.arange(n_fft)[:, None] + hop * np.arange(F)[None, :]
+    return np.fft.rfft(win * yp[idx], axis=0).astype(np.complex64)
+
+
+def test_stft_head_tail_split_equals_whole_signal_padding_where_it_should():
+    """librosa 0.10 pads slices of the signal for the head and tail frames.  With zero padding that
+    equals padding the whole signal for every shape; with 'reflect' it does for hop < n_fft / 2."""
+    import warnings
+
+    rng = np.random.default_rng(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(300):
+            n_fft = int(rng.choice([64, 128, 256, 512]))
+            hop = int(rng.integers(1, n_fft + 8))
+            T = int(rng.integers(2, 6 * n_fft))
+            y = rng.standard_normal(T).astype(np.float32)
+            a = R.stft(y, n_fft=n_fft, hop_length=hop, pad_mode="constant")
+            assert a.shape == (1 + n_fft // 2, 1 + T // hop)
+            assert np.array_equal(a, _stft_whole_signal_padding(y, n_fft, hop, "constant")), (n_fft, hop, T)
+            b = R.stft(y, n_fft=n_fft, hop_length=hop, pad_mode="reflect")
+            if hop < n_fft // 2:
+                assert np.array_equal(b, _stft_whole_signal_padding(y, n_fft, hop, "reflect")), (n_fft, hop, T)
+
+
+def _short_tail_length(n_fft, hop, around):
+    """A signal length >= around whose last frame librosa pads from a slice of exactly n_fft/2
+    samples: a multiple of the hop (a tail frame starts n_fft/2 before the signal's end), with the
+    frames that touch the left padding and those that touch the right padding distinct."""
+    half = n_fft // 2
+    for T in range(around, around + 2 * hop):
+        tail_k = (T + half - n_fft) // hop + 1
+        L = T - (tail_k * hop - half)
+        if int(np.ceil(half / hop)) < tail_k <= T // hop and L == half:
+            return T
+    raise AssertionError("no such length")
+
+
+@pytest.mark.parametrize("n_fft,hop,around", [(512, 400, 1990), (2048, 1024, 5000), (256, 250, 1130), (480, 240, 3000)])
+def test_stft_reflect_tail_slice_shorter_than_the_padding(n_fft, hop, around):
+    """hop >= n_fft / 2, pad_mode='reflect', signal length a multiple of the hop: the last frame is
+    padded from y[tail_k hop - n_fft/2:], a slice of exactly n_fft/2 samples -- one fewer than a
+    reflection of n_fft/2 samples needs -- so numpy turns round inside the slice for the frame's very
+    last sample.  Checked against that statement written out sample by sample; the result differs
+    from a reflection of the whole signal in that one sample of that one frame (under a window
+    weight of about 1e-6)."""
+    rng = np.random.default_rng(n_fft + hop)
+    T = _short_tail_length(n_fft, hop, around)
+    y = rng.standard_normal(T).astype(np.float32)
+    half = n_fft // 2
+    tail_k = (T + half - n_fft) // hop + 1
+    lo = tail_k * hop - half
+    L = T - lo
+    got = R.stft(y, n_fft=n_fft, hop_length=hop, pad_mode="reflect")
+    win = R.get_window("hann", n_fft, fftbins=True)
+    F = 1 + T // hop
+    assert got.shape[-1] == F
+    whole = _stft_whole_signal_padding(y, n_fft, hop, "reflect")
+    for t in range(F):
+        idx = t * hop - half + np.arange(n_fft)
+        if t >= tail_k:                     # reflect inside y[lo:]: period 2 (L - 1)
+            m = np.mod(idx - lo, 2 * (L - 1))
+            src = lo + np.where(m < L, m, 2 * (L - 1) - m)
+        else:                               # head and middle frames: the signal's own start
+            m = np.mod(idx, 2 * (T - 1))
+            src = np.where(m < T, m, 2 * (T - 1) - m)
+        want = np.fft.rfft(win * y[src]).astype(np.complex64)
+        assert np.array_equal(got[:, t], want), t
+    assert np.array_equal(got[:, :tail_k], whole[:, :tail_k])
+    d = np.abs(got[:, tail_k:] - whole[:, tail_k:]).max() / np.abs(whole[:, tail_k:]).max()
+    assert d < 1e-4

@@ -1,6 +1,6 @@
 """Runs the pipeline a few times on a small batch; meant to be run under rocprofv3 --pmc.
 
-    python tools/prof_front.py [hours] [iterations] [ref|asr512|asr400|fft1024]"""
+    python tools/prof_front.py [hours] [iterations] [ref|asr512|asr400|fft1024|fft600]"""
 import sys
 from pathlib import Path
 import torch
@@ -15,7 +15,8 @@ which = sys.argv[3] if len(sys.argv) > 3 else "ref"
 cfg = {"ref": S.MfccConfig.reference_default(),
        "asr512": S.make_config(sr=16000, n_fft=512, win_length=400, hop_length=160, n_mels=80, n_mfcc=13),
        "asr400": S.make_config(sr=16000, n_fft=400, hop_length=160, n_mels=80, n_mfcc=13),
-       "fft1024": S.make_config(sr=16000, n_fft=1024, hop_length=256, n_mels=80, n_mfcc=13)}[which]
+       "fft1024": S.make_config(sr=16000, n_fft=1024, hop_length=256, n_mels=80, n_mfcc=13),
+       "fft600": S.make_config(sr=16000, n_fft=600, hop_length=160, n_mels=80, n_mfcc=13)}[which]
 pcm, so = make_batch(hours, 1234, dev)
 plan = S.MfccPlan(cfg, dev)
 fo = plan.frame_offsets(so)
