@@ -100,12 +100,21 @@ def test_bench_launches_its_own_ranks():
     that the launcher, the rendezvous and the max-over-ranks timing run on CPU (gloo)."""
     import json
 
-    r = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1"], {"BENCH_STUB": "1"})
+    r = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--strong-hours", "5"], {"BENCH_STUB": "1"})
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0
+    assert len(line["per_rank_ms"]) == 2 and all(t > 0 for t in line["per_rank_ms"])
+    # the fixed-corpus leg: one corpus, sharded longest-first, every hour counted once
+    st = line["strong"]
+    assert st["scaling"] == "strong" and len(st["per_rank_seconds"]) == 2
+    assert abs(sum(st["per_rank_audio_hours"]) - st["audio_hours"]) < 1e-9 and abs(st["audio_hours"] - 5.0) < 0.02
+    assert 1.0 <= st["lpt_imbalance"] < 1.01
+    # the engine's one collective: both ranks seen, all-reduced statistics equal the gathered sum
+    assert line["rccl"]["ranks_seen"] == 2 and line["rccl"]["cmvn_allreduce_ok"] and line["rccl"]["bytes"] == 216
+    assert line["rccl"]["frames_all_ranks"] == 300.0
 
 
 def test_bench_launcher_reports_a_failed_rank():

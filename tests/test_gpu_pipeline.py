@@ -405,10 +405,19 @@ def test_bench_under_torchrun_initialises_rccl(gpu):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", "29517", str(root / "bench.py"), "--gpus", "1",
-                        "--steps", "5", "--warmup", "2", "--hours", "0.5", "--no-cpu-baseline"],
+                        "--steps", "5", "--warmup", "2", "--hours", "0.5", "--no-cpu-baseline",
+                        "--strong-hours", "20", "--batch-gb", "0.5", "--sustain-seconds", "0.2"],
                        env=env, capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert len(line["per_rank_ms"]) == 1
+    # the legs a launcher adds: the fixed-corpus (strong-scaling) workload in several batches through
+    # one workspace, the CMVN statistics through the process group, the sustained run
+    st = line["strong"]
+    assert st["scaling"] == "strong" and abs(st["audio_hours"] - 20.0) < 0.05 and st["per_rank_batches"][0] >= 9
+    assert st["audio_hours_per_s"] > 0 and len(st["per_rank_seconds"]) == 1
+    assert line["rccl"]["ranks_seen"] == 1 and line["rccl"]["cmvn_allreduce_ok"]
+    assert line["sustained"]["steps"] >= 5 and line["sustained"]["audio_hours_per_s"] > 0
