@@ -69,6 +69,7 @@ def soak(seconds: float, seed: int, max_batches: int = 0):
     dev = torch.device("cuda", 0)
     t_end = time.time() + seconds
     n, worst, worst_kw = 0, 0.0, None
+    worst_short = None
     used, t_say = {}, time.time() + 30.0
     while time.time() < t_end and not (max_batches and n >= max_batches):
         n_fft = int(rng.choice([2048, 2048, 2048, 1024, 960, 800, 640, 512, 480, 400, 320, 256]))
@@ -141,14 +142,20 @@ def soak(seconds: float, seed: int, max_batches: int = 0):
             # utterances are compared with the oracle instead (as tests/test_gpu_parity.py pins them).
             d = np.abs(a - c)
             short = np.zeros(len(d), dtype=bool)
-            err_short = 0.0
+            err_short, worst_short = 0.0, None
             if kw["pad_mode"] == "reflect":
                 for u, L in enumerate(lens):
                     if L < n_fft:
                         short[int(fo[u]):int(fo[u + 1])] = True
-                        if groups is None:      # (utterances sharing a top_db maximum have no oracle of their own)
+                        # (utterances sharing a top_db maximum have no oracle of their own; and with
+                        # power < 2 the top_db window -- 80 dB on MAGNITUDES is 160 dB of power -- reaches
+                        # below float32's resolution of about -138 dB re the frame's peak, where a line
+                        # spectrum's side lobes are rounding noise in any float32 transform)
+                        if groups is None and kw.get("power", 2.0) >= 2.0:
                             want = R.mfcc(y=ys[u], **kw).T
-                            err_short = max(err_short, float(np.abs(a[int(fo[u]):int(fo[u + 1])] - want).max()))
+                            e_u = float(np.abs(a[int(fo[u]):int(fo[u + 1])] - want).max())
+                            if e_u > err_short:
+                                err_short, worst_short = e_u, (u, L)
             err = max(float(d[~short].max()) if (~short).any() else 0.0, err_short)
         else:
             u = int(rng.integers(0, n_utts))
@@ -157,7 +164,8 @@ def soak(seconds: float, seed: int, max_batches: int = 0):
         gain = 1.0 if kw.get("norm", "ortho") == "ortho" else 2.0 * np.sqrt(kw["n_mels"])   # unnormalised DCT
         gain *= 1.0 + 0.5 * kw.get("lifter", 0)
         err /= gain
-        assert err <= 1e-2, f"mismatch {err} dB: {kw}, lens {lens[:8]}..."
+        assert err <= 1e-2, (f"mismatch {err} dB: {kw}, lens {lens[:8]}..., worst short utterance (index, length) "
+                             f"{worst_short if plan.front_kernel != 'fft2048' else None}")
         if err > worst:
             worst, worst_kw = err, dict(kw, kernel=plan.front_kernel, scale=float(np.abs(ys[0]).max()))
         used[plan.front_kernel] = used.get(plan.front_kernel, 0) + 1
