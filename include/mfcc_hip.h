@@ -262,7 +262,27 @@ int mfcc_host_write_feature_files(int32_t n_files, const char* const* paths, con
                                   const float* const* h_data, const int64_t* rows, int64_t cols, int32_t n_attrs,
                                   const char* const* attr_names, const int32_t* attr_is_string,
                                   const int64_t* attr_ints, const char* const* attr_strings);
+/* The same with the files dealt to n_threads host threads (file creation is system-call bound;
+ * n_threads <= 1 writes them in order on the caller's thread).  The drop-in step writes one file
+ * per utterance (/root/reference/src/preprocess.py:138-144 inside the loop at :155-167): after
+ * the GPU path that is where its wall clock goes. */
+int mfcc_host_write_feature_files_mt(int32_t n_files, const char* const* paths, const char* dataset_name,
+                                     const float* const* h_data, const int64_t* rows, int64_t cols, int32_t n_attrs,
+                                     const char* const* attr_names, const int32_t* attr_is_string,
+                                     const int64_t* attr_ints, const char* const* attr_strings, int32_t n_threads);
 const char* mfcc_host_file_error(void);
+
+/* ---- host helper: packing a ragged batch for upload ----------------------------------------- */
+/* Copies the samples [a, b) of the concatenation of n_utts host utterances -- srcs[u] holds
+ * offsets[u + 1] - offsets[u] elements, offsets[0] = 0 -- to dst[a - c0 ..], dst being a staging
+ * buffer (pinned host memory) that starts at sample c0 of the concatenation.  mode 0: float32
+ * samples copied; 1: int16 PCM copied; 2: float32 samples on the int16 grid converted to int16 as
+ * mfcc_host_pcm16_from_float does.  Returns 1, or 0 when mode 2 meets a sample off the grid (dst is
+ * then not to be used), negative on bad arguments.  Replaces the per-utterance hand-over of
+ * /root/reference/src/preprocess.py:132-134 (one host array per librosa call) by one device
+ * buffer per batch.  Host memory only; thread-safe: callers split [c0, c1) over their threads. */
+int mfcc_host_pack_range(const void* const* srcs, const int64_t* offsets, int64_t n_utts, void* dst, int64_t c0,
+                         int64_t a, int64_t b, int32_t mode);
 
 #ifdef __cplusplus
 }

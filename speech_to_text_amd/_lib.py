@@ -111,6 +111,11 @@ SYMBOLS = {
     "mfcc_host_write_feature_files": (C.c_int, [C.c_int32, C.POINTER(C.c_char_p), C.c_char_p, C.POINTER(C.c_void_p),
                                                 C.POINTER(C.c_int64), C.c_int64, C.c_int32, C.POINTER(C.c_char_p),
                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]),
+    "mfcc_host_write_feature_files_mt": (C.c_int, [C.c_int32, C.POINTER(C.c_char_p), C.c_char_p, C.c_void_p,
+                                                   C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_char_p),
+                                                   C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_char_p), C.c_int32]),
+    "mfcc_host_pack_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                       C.c_int32]),
     "mfcc_host_file_error": (C.c_char_p, []),
     "mfcc_cmvn_accumulate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "mfcc_cmvn_apply": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_double,

@@ -7,7 +7,7 @@
 //   rdft32 : 32-point DFT of a REAL sequence (bins 0..16) from one cfft16 of the packed
 //            sequence z[m] = r[2m] + i r[2m+1] plus the conjugate-symmetric split.
 //   rdft_cols<R> : the same for 2R = 4, 8, 16 points;  rdft25 : 25-point real DFT (5 x 5);
-//   rdft_even<A> : 20-, 30-, 40-, 50- and 60-point real DFTs, folded direct sums.
+//   rdft_even<A> : real DFTs of any even length A (8 .. 62 are used), folded direct sums.
 //
 // Forward transform convention, as numpy.fft: X[k] = sum_n x[n] exp(-2 pi i n k / N).
 #pragma once
@@ -448,14 +448,58 @@ constexpr float S60[60] = {
     -0.8660254037844386f, -0.8090169943749476f, -0.743144825477394f, -0.6691306063588581f, -0.5877852522924734f,
     -0.49999999999999967f, -0.40673664307580015f, -0.3090169943749476f, -0.20791169081775898f, -0.10452846326765342f};
 
-template <int A> struct TrigTable;
-template <> struct TrigTable<20> { static constexpr const float* c() { return C20; } static constexpr const float* s() { return S20; } };
-template <> struct TrigTable<30> { static constexpr const float* c() { return C30; } static constexpr const float* s() { return S30; } };
-template <> struct TrigTable<40> { static constexpr const float* c() { return C40; } static constexpr const float* s() { return S40; } };
-template <> struct TrigTable<50> { static constexpr const float* c() { return C50; } static constexpr const float* s() { return S50; } };
-template <> struct TrigTable<60> { static constexpr const float* c() { return C60; } static constexpr const float* s() { return S60; } };
+// cos and sin of 2 pi j / A for 0 <= j < A, evaluated in double precision from the octant
+// symmetries (exact integer comparisons) and the Taylor series on [0, pi / 4] (truncation error
+// below 1e-20); used at compile time only (TrigArray).
+FC_HD constexpr double trig_octant(int num, int den, bool want_sin) {
+    // angle x = 2 pi num / den with 0 <= 8 num <= den, i.e. x in [0, pi / 4]
+    const double x = 6.283185307179586476925286766559 * (double)num / (double)den;
+    const double x2 = x * x;
+    double term = want_sin ? x : 1.0, sum = term;
+    for (int n = 1; n <= 11; ++n) {
+        const int k = want_sin ? 2 * n + 1 : 2 * n;
+        term = -term * x2 / (double)((k - 1) * k);
+        sum += term;
+    }
+    return sum;
+}
+FC_HD constexpr double trig_unit(int j, int A, bool want_sin) {
+    // reduce j / A (a fraction of a turn) to the first octant
+    int num = j % A, den = A;
+    double sign_c = 1.0, sign_s = 1.0;
+    if (2 * num > den) { num = den - num; sign_s = -sign_s; }             // x -> 2 pi - x
+    if (4 * num > den) { num = den - 2 * num; den *= 2; sign_c = -sign_c; }   // x -> pi - x (as num / (2 den'))
+    // now 0 <= num / den <= 1/4
+    if (8 * num > den) {                                                   // x -> pi / 2 - x swaps cos and sin
+        num = den - 4 * num; den *= 4;
+        return want_sin ? sign_s * trig_octant(num, den, false) : sign_c * trig_octant(num, den, true);
+    }
+    return want_sin ? sign_s * trig_octant(num, den, true) : sign_c * trig_octant(num, den, false);
+}
 
-// Real A-point DFT for even A (20, 30, 40, 50, 60), bins 0 .. A/2: Y[c] = sum_a x[a] exp(-2 pi i a c / A), by
+// cos / sin of 2 pi j / A as float: literal tables for the lengths that had them first (their
+// values stay as they were), the series for every other length.
+template <int A> struct TrigArray {
+    float c[A], s[A];
+    constexpr TrigArray() : c(), s() {
+        for (int j = 0; j < A; ++j) {
+            c[j] = (float)trig_unit(j, A, false);
+            s[j] = (float)trig_unit(j, A, true);
+        }
+    }
+};
+template <int A> struct TrigTable {
+    static constexpr TrigArray<A> t{};       // evaluated by the compiler's front end: a table of literals
+    static FC_HD constexpr float cosv(int j) { return t.c[j]; }
+    static FC_HD constexpr float sinv(int j) { return t.s[j]; }
+};
+template <> struct TrigTable<20> { static FC_HD constexpr float cosv(int j) { return C20[j]; } static FC_HD constexpr float sinv(int j) { return S20[j]; } };
+template <> struct TrigTable<30> { static FC_HD constexpr float cosv(int j) { return C30[j]; } static FC_HD constexpr float sinv(int j) { return S30[j]; } };
+template <> struct TrigTable<40> { static FC_HD constexpr float cosv(int j) { return C40[j]; } static FC_HD constexpr float sinv(int j) { return S40[j]; } };
+template <> struct TrigTable<50> { static FC_HD constexpr float cosv(int j) { return C50[j]; } static FC_HD constexpr float sinv(int j) { return S50[j]; } };
+template <> struct TrigTable<60> { static FC_HD constexpr float cosv(int j) { return C60[j]; } static FC_HD constexpr float sinv(int j) { return S60[j]; } };
+
+// Real A-point DFT for even A (8 .. 62), bins 0 .. A/2: Y[c] = sum_a x[a] exp(-2 pi i a c / A), by
 // the direct sum folded twice.  With H = A/2, p[a] = x[a] + x[A-a] and q[a] = x[a] - x[A-a]
 // (a = 1 .. H-1),
 //     Re Y[c] = x[0] + (-1)^c x[H] + sum_a p[a] cos(2 pi a c / A),   Im Y[c] = -sum_a q[a] sin(2 pi a c / A);
@@ -487,7 +531,7 @@ FC_HD void rdft_even(const float (&x)[A], float (&yr)[A / 2 + 1], float (&yi)[A 
         }
 #pragma unroll
         for (int a = 1; a <= M; ++a) {
-            const float cs = TrigTable<A>::c()[(a * c) % A], sn = TrigTable<A>::s()[(a * c) % A];
+            const float cs = TrigTable<A>::cosv((a * c) % A), sn = TrigTable<A>::sinv((a * c) % A);
             re = fmaf((c % 2 == 0) ? pe[a] : po[a], cs, re);
             im = fmaf((c % 2 == 0) ? qe[a] : qo[a], sn, im);
         }

@@ -33,6 +33,9 @@ constexpr size_t fast_lds_bytes(int waves, int n_jobs) {
 #ifndef MFCC_FAST_TW1Q
 #define MFCC_FAST_TW1Q 1
 #endif
+#ifndef MFCC_FAST_EDGE_DIRECT
+#define MFCC_FAST_EDGE_DIRECT 1
+#endif
 // experiment: issue priority per stage, two bits each: step 1 (bits 0-1), step 2 (2-3), power store and
 // column 0 (4-5), mel stage (6-7)
 #ifndef MFCC_FAST_PRIO
@@ -194,8 +197,33 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
 
         // ---- samples, window, step 1: real DFT-32 over n2, twiddle, exchange -------------------------
         // both paths give all 32 sample registers new values, so last frame's are dead here
+#if MFCC_FAST_EDGE_DIRECT
+        // Zero padding (librosa 0.10's default, the reference's): an edge frame loads like an
+        // interior one, from addresses clamped into the utterance, and the lanes that fell outside
+        // it take 0 -- all 32 loads in flight at once instead of a rolled loop through LDS.
+        const bool direct = !interior && !(a.reflect && a.pad) && tc.T > 0;
+#else
+        const bool direct = false;
+#endif
         if (interior) {
             load_samples(tc.soff, t);
+        } else if (direct) {
+            const int first = t * a.hop - a.pad + lane;
+            const int last = tc.T - 1;
+            if (PCM16) {
+                const int16_t* pp = static_cast<const int16_t*>(a.pcm) + tc.soff;
+#pragma unroll
+                for (int n2 = 0; n2 < 32; ++n2)
+                    smp[n2] = __builtin_bit_cast(float, (int)pp[min(max(first + 64 * n2, 0), last)]);
+            } else {
+                const float* pp = static_cast<const float*>(a.pcm) + tc.soff;
+#pragma unroll
+                for (int n2 = 0; n2 < 32; ++n2) smp[n2] = pp[min(max(first + 64 * n2, 0), last)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n2 = 0; n2 < 32; ++n2)
+                smp[n2] = ((unsigned)(first + 64 * n2) <= (unsigned)last) ? smp[n2] : 0.0f;
         } else {
             stage_edge_frame(X, a.pcm, tc.soff, PCM16, t * a.hop - a.pad, tc.T, a.reflect && a.pad, lane, a.hop);
 #pragma unroll
@@ -212,7 +240,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_2048_fast(const FrontArg
                 wv[4 * j] = w4.x; wv[4 * j + 1] = w4.y; wv[4 * j + 2] = w4.z; wv[4 * j + 3] = w4.w;
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (PCM16 && interior) {
+            if (PCM16 && (interior || direct)) {
 #pragma unroll
                 for (int n2 = 0; n2 < 32; ++n2) smp[n2] = PCM16_SCALE * (float)__builtin_bit_cast(int, smp[n2]);
             }

@@ -1,7 +1,8 @@
-// Front end for n_fft = 16 A with A = 20, 25, 30, 40, 50, 60 (n_fft = 320, 400, 480, 640, 800, 960:
-// the 20 .. 60 ms windows of 16 kHz speech front ends -- or 25 / 20 ms ones at 32 / 48 kHz -- taken
-// as the transform length, e.g. n_fft = 400, hop 160, 80 mels) on gfx950: one wavefront per four consecutive frames, no barriers in the
-// frame loop.
+// Front end for n_fft = 16 A with A = 25 or any even A from 8 to 62 that is not a power of two
+// (built: n_fft = 128, 160, 192, 320, 384, 400, 480, 576, 640, 768, 800, 960 -- the 8 .. 60 ms
+// windows of 16 kHz speech front ends, or shorter ones at 32 / 48 kHz, taken as the transform
+// length, e.g. n_fft = 400, hop 160, 80 mels) on gfx950: one wavefront per four consecutive
+// frames, no barriers in the frame loop.
 //
 //   pad / frame / window -> N-point real DFT (A x 16) -> |X|^power -> sparse mel filterbank
 //
@@ -29,7 +30,7 @@
 #include "front_pow2.h"
 
 #ifndef MFCC_16A_WIN_LDS
-#define MFCC_16A_WIN_LDS ((1ULL << 30) | (1ULL << 40) | (1ULL << 50) | (1ULL << 60))
+#define MFCC_16A_WIN_LDS (~0ULL << 30)
 #endif
 
 namespace k16a {
@@ -37,8 +38,7 @@ constexpr int T = 4;                    // frames per wavefront pass
 constexpr int COL = 36;                 // floats per exchange column: 16 complex + 4 floats of padding
 template <int A>
 struct Geo {
-    static_assert(A == 20 || A == 25 || A == 30 || A == 40 || A == 50 || A == 60,
-                  "supported: n_fft = 320, 400, 480, 640, 800, 960");
+    static_assert(A == 25 || (A % 2 == 0 && A >= 8 && A <= 62), "supported: n_fft = 400 and 16 x an even number in 8 .. 62");
     static constexpr int N = 16 * A, NB = N / 2 + 1, NA = A, NC = A / 2 + 1;   // NC columns per frame
     static constexpr int ROUNDS = (T * NC + 63) / 64;                          // step-2 columns per lane
     static_assert(ROUNDS <= 2, "at most two columns per lane");
@@ -51,8 +51,8 @@ struct Geo {
     static constexpr int p_base(int t) { return P_STRIDE * t; }
     // The window: A registers per lane, or (bit A of MFCC_16A_WIN_LDS) a table in LDS as [b][a],
     // rows WIN_ROW floats apart -- a multiple of 4 whose quarter is odd, so that the 16-byte reads
-    // of the 16 residues b fall into 16 different bank groups.  Default: LDS at A = 30, where the
-    // 30 registers are what the kernel spills, and at A >= 40.
+    // of the 16 residues b fall into 16 different bank groups.  Default: LDS from A = 30 on, where
+    // the window's registers are what the kernel would spill.
     static constexpr bool WIN_LDS = ((unsigned long long)(MFCC_16A_WIN_LDS) >> A) & 1;
     static constexpr int WIN_ROW = ((A + 3) / 4) % 2 ? (A + 3) / 4 * 4 : (A + 3) / 4 * 4 + 4;
     static constexpr int WIN_FLOATS = WIN_LDS ? 16 * WIN_ROW : 0;

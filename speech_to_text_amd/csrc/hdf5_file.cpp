@@ -8,11 +8,16 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <sys/types.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include "../../include/mfcc_hip.h"
@@ -77,16 +82,32 @@ Bytes object_header(const Bytes& messages, uint16_t n) {
 
 thread_local std::string g_file_err;
 
-}  // namespace
+// "<directory of path>.partial", or "" for a path without a directory part
+std::string side_dir_of(const std::string& full) {
+    const size_t slash = full.find_last_of('/');
+    if (slash == std::string::npos || slash == 0) return std::string();
+    std::string dir = full.substr(0, slash);
+    while (dir.size() > 1 && dir.back() == '/') dir.pop_back();
+    return dir + ".partial";
+}
 
-extern "C" {
+// All of `iov` to fd (writev may stop short).
+bool write_all(int fd, struct iovec* iov, int n) {
+    while (n > 0) {
+        ssize_t w = ::writev(fd, iov, n);
+        if (w < 0) return false;
+        while (n > 0 && (size_t)w >= iov->iov_len) { w -= (ssize_t)iov->iov_len; ++iov; --n; }
+        if (n > 0) { iov->iov_base = static_cast<char*>(iov->iov_base) + w; iov->iov_len -= (size_t)w; }
+    }
+    return true;
+}
 
-const char* mfcc_host_file_error(void) { return g_file_err.c_str(); }
-
-int mfcc_host_write_feature_file(const char* path, const char* dataset_name, const float* h_data, int64_t rows,
-                                 int64_t cols, int32_t n_attrs, const char* const* attr_names,
-                                 const int32_t* attr_is_string, const int64_t* attr_ints,
-                                 const char* const* attr_strings) {
+// side_ready: the caller has already created the side directory of the temporaries (batch writes
+// create it once instead of once per file).
+int write_one(const char* path, const char* dataset_name, const float* h_data, int64_t rows,
+              int64_t cols, int32_t n_attrs, const char* const* attr_names,
+              const int32_t* attr_is_string, const int64_t* attr_ints,
+              const char* const* attr_strings, bool side_ready) {
     if (!path || !dataset_name || rows < 0 || cols < 0 || n_attrs < 0 || (rows * cols > 0 && !h_data) ||
         (n_attrs > 0 && (!attr_names || !attr_is_string || !attr_ints || !attr_strings))) {
         g_file_err = "bad arguments";
@@ -210,68 +231,160 @@ int mfcc_host_write_feature_file(const char* path, const char* dataset_name, con
     // leaves its half-written file there, where no reader walks.  A path without a directory part
     // has no sibling to use and takes "<path>.tmp".
     const std::string full(path);
-    const size_t slash = full.find_last_of('/');
-    std::string tmp, side;
-    if (slash == std::string::npos || slash == 0) {
+    const std::string side = side_dir_of(full);
+    std::string tmp;
+    if (side.empty()) {
         tmp = full + ".tmp";
     } else {
-        std::string dir = full.substr(0, slash);
-        while (dir.size() > 1 && dir.back() == '/') dir.pop_back();
-        side = dir + ".partial";
-        (void)::mkdir(side.c_str(), 0777);
-        tmp = side + "/" + full.substr(slash + 1) + "." + std::to_string((long)::getpid());
+        if (!side_ready) (void)::mkdir(side.c_str(), 0777);
+        tmp = side + "/" + full.substr(full.find_last_of('/') + 1) + "." + std::to_string((long)::getpid());
     }
-    FILE* fp = std::fopen(tmp.c_str(), "wb");
-    if (!fp && !side.empty()) {          // another writer removed the (then empty) side directory meanwhile
+    int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    if (fd < 0 && !side.empty()) {          // another writer removed the (then empty) side directory meanwhile
         (void)::mkdir(side.c_str(), 0777);
-        fp = std::fopen(tmp.c_str(), "wb");
+        fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
     }
-    if (!fp) {
+    if (fd < 0) {
         g_file_err = std::string("cannot open ") + tmp;
         return MFCC_E_INVALID;
     }
-    bool ok = std::fwrite(f.data(), 1, f.size(), fp) == f.size();
-    if (nbytes) ok = ok && std::fwrite(h_data, 1, nbytes, fp) == nbytes;
+    // metadata, dataset and padding leave in one system call
     static const char pad[8] = {0};
-    if (nbytes % 8) ok = ok && std::fwrite(pad, 1, 8 - nbytes % 8, fp) == 8 - nbytes % 8;
-    ok = (std::fclose(fp) == 0) && ok;
+    struct iovec iov[3];
+    int n_iov = 0;
+    iov[n_iov].iov_base = const_cast<char*>(f.data()); iov[n_iov].iov_len = f.size(); ++n_iov;
+    if (nbytes) { iov[n_iov].iov_base = const_cast<float*>(h_data); iov[n_iov].iov_len = (size_t)nbytes; ++n_iov; }
+    if (nbytes % 8) { iov[n_iov].iov_base = const_cast<char*>(pad); iov[n_iov].iov_len = (size_t)(8 - nbytes % 8); ++n_iov; }
+    bool ok = write_all(fd, iov, n_iov);
+    ok = (::close(fd) == 0) && ok;
     if (!ok) {
-        std::remove(tmp.c_str());
+        (void)::unlink(tmp.c_str());
         g_file_err = std::string("short write to ") + tmp;
         return MFCC_E_INVALID;
     }
-    if (std::rename(tmp.c_str(), path) != 0) {
-        std::remove(tmp.c_str());
+    if (::rename(tmp.c_str(), path) != 0) {
+        (void)::unlink(tmp.c_str());
         g_file_err = std::string("cannot rename ") + tmp + " to " + path;
         return MFCC_E_INVALID;
     }
     return MFCC_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+const char* mfcc_host_file_error(void) { return g_file_err.c_str(); }
+
+int mfcc_host_write_feature_file(const char* path, const char* dataset_name, const float* h_data, int64_t rows,
+                                 int64_t cols, int32_t n_attrs, const char* const* attr_names,
+                                 const int32_t* attr_is_string, const int64_t* attr_ints,
+                                 const char* const* attr_strings) {
+    return write_one(path, dataset_name, h_data, rows, cols, n_attrs, attr_names, attr_is_string, attr_ints,
+                     attr_strings, false);
+}
+
 int mfcc_host_write_feature_files(int32_t n_files, const char* const* paths, const char* dataset_name,
                                   const float* const* h_data, const int64_t* rows, int64_t cols, int32_t n_attrs,
                                   const char* const* attr_names, const int32_t* attr_is_string,
                                   const int64_t* attr_ints, const char* const* attr_strings) {
+    return mfcc_host_write_feature_files_mt(n_files, paths, dataset_name, h_data, rows, cols, n_attrs, attr_names,
+                                            attr_is_string, attr_ints, attr_strings, 1);
+}
+
+int mfcc_host_write_feature_files_mt(int32_t n_files, const char* const* paths, const char* dataset_name,
+                                     const float* const* h_data, const int64_t* rows, int64_t cols, int32_t n_attrs,
+                                     const char* const* attr_names, const int32_t* attr_is_string,
+                                     const int64_t* attr_ints, const char* const* attr_strings, int32_t n_threads) {
     if (n_files < 0 || (n_files > 0 && (!paths || !h_data || !rows))) {
         g_file_err = "bad arguments";
         return MFCC_E_INVALID;
     }
+    if (n_files == 0) return MFCC_OK;
+    for (int32_t i = 0; i < n_files; ++i)
+        if (!paths[i]) {
+            g_file_err = "bad arguments";
+            return MFCC_E_INVALID;
+        }
+    // the side directories of the temporaries: created once per distinct directory, not per file
+    std::vector<std::string> sides;
     for (int32_t i = 0; i < n_files; ++i) {
-        const int rc = mfcc_host_write_feature_file(paths[i], dataset_name, h_data[i], rows[i], cols, n_attrs, attr_names,
-                                                    attr_is_string, attr_ints + (size_t)i * n_attrs,
-                                                    attr_strings + (size_t)i * n_attrs);
-        if (rc != MFCC_OK) return rc;
-    }
-    if (n_files > 0) {      // the side directory of the temporaries, if this batch left it empty
-        const std::string full(paths[0]);
-        const size_t slash = full.find_last_of('/');
-        if (slash != std::string::npos && slash > 0) {
-            std::string dir = full.substr(0, slash);
-            while (dir.size() > 1 && dir.back() == '/') dir.pop_back();
-            (void)::rmdir((dir + ".partial").c_str());
+        const std::string side = side_dir_of(paths[i]);
+        if (!side.empty() && (sides.empty() || sides.back() != side)) {
+            bool seen = false;
+            for (const std::string& s : sides) seen = seen || s == side;
+            if (!seen) {
+                (void)::mkdir(side.c_str(), 0777);
+                sides.push_back(side);
+            }
         }
     }
+    // files are handed out one at a time from a shared counter; the first failure stops the hand-out
+    std::atomic<int32_t> next(0);
+    std::atomic<int> status(MFCC_OK);
+    std::string first_err;
+    std::atomic_flag err_lock = ATOMIC_FLAG_INIT;
+    auto work = [&]() {
+        for (;;) {
+            const int32_t i = next.fetch_add(1);
+            if (i >= n_files || status.load() != MFCC_OK) return;
+            const int rc = write_one(paths[i], dataset_name, h_data[i], rows[i], cols, n_attrs, attr_names, attr_is_string,
+                                     attr_ints + (size_t)i * n_attrs, attr_strings + (size_t)i * n_attrs, true);
+            if (rc != MFCC_OK) {
+                while (err_lock.test_and_set()) {}
+                if (status.load() == MFCC_OK) { first_err = g_file_err; status.store(rc); }
+                err_lock.clear();
+                return;
+            }
+        }
+    };
+    const int T = std::max(1, std::min<int>({n_threads, n_files, 64}));
+    if (T == 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        pool.reserve(T - 1);
+        for (int t = 1; t < T; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread& th : pool) th.join();
+    }
+    for (const std::string& s : sides) (void)::rmdir(s.c_str());   // succeeds only if this batch left it empty
+    if (status.load() != MFCC_OK) {
+        g_file_err = first_err;      // (the failing thread's message, for the caller's thread)
+        return status.load();
+    }
     return MFCC_OK;
+}
+
+/* Packs the samples [a, b) of the concatenation of n_utts host utterances (srcs[u] holds
+ * offsets[u+1] - offsets[u] elements) into dst[a - c0 ...].  mode 0: float32 -> float32,
+ * 1: int16 -> int16, 2: float32 on the int16 grid -> int16 (returns 0 if a sample is off the grid). */
+int mfcc_host_pack_range(const void* const* srcs, const int64_t* offsets, int64_t n_utts, void* dst, int64_t c0,
+                         int64_t a, int64_t b, int32_t mode) {
+    if (!srcs || !offsets || !dst || n_utts <= 0 || a < c0 || b < a || mode < 0 || mode > 2) return a == b ? 1 : -1;
+    // the utterance that holds sample a
+    int64_t lo = 0, hi = n_utts;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) / 2;
+        if (offsets[mid] <= a) lo = mid; else hi = mid;
+    }
+    int64_t u = lo;
+    while (a < b) {
+        while (u + 1 < n_utts && offsets[u + 1] <= a) ++u;
+        const int64_t e = std::min<int64_t>(b, offsets[u + 1]);
+        const int64_t n = e - a, at = a - offsets[u];
+        if (n <= 0) return -1;
+        if (mode == 0) {
+            std::memcpy(static_cast<float*>(dst) + (a - c0), static_cast<const float*>(srcs[u]) + at, (size_t)n * 4);
+        } else if (mode == 1) {
+            std::memcpy(static_cast<int16_t*>(dst) + (a - c0), static_cast<const int16_t*>(srcs[u]) + at, (size_t)n * 2);
+        } else {
+            if (mfcc_host_pcm16_from_float(static_cast<const float*>(srcs[u]) + at, n, static_cast<int16_t*>(dst) + (a - c0)) != 1)
+                return 0;
+        }
+        a = e;
+    }
+    return 1;
 }
 
 }  // extern "C"

@@ -718,17 +718,25 @@ Pow2Fn k16a_pick(bool pw2, bool pcm16) {
     if (pw2) return pcm16 ? k_melspec_16a<A, W, 0, true> : k_melspec_16a<A, W, 0, false>;
     return pcm16 ? k_melspec_16a<A, W, 1, true> : k_melspec_16a<A, W, 1, false>;
 }
-// small_fft: 8, 9, 10 for the power-of-two kernels; 320, 400, 480, 640, 800, 960 for the 16 A kernels
-// (front_400.h; at 640 the regions are 12 KB and 12 wavefronts are the most that fit, at 800 and
-// 960 eight)
+// small_fft: 8, 9, 10 for the power-of-two kernels; n_fft itself for the 16 A kernels (front_400.h).
+// Wavefronts per workgroup follow the region size and the registers the A-point transform needs:
+// 16 up to A = 30, 12 up to A = 40 (12 KB regions), 8 beyond; 8 is also the fallback of the
+// lengths that were built first when a large filterbank leaves less LDS.
+#define MFCC_16A_LENGTHS(X) X(8) X(10) X(12) X(20) X(24) X(25) X(30) X(36) X(40) X(48) X(50) X(60)
+constexpr int k16a_waves(int A) { return A <= 30 ? 16 : (A <= 40 ? 12 : 8); }
+constexpr bool k16a_has_fallback(int A) { return A == 20 || A == 25 || A == 30 || A == 40; }
+template <int A>
+Pow2Fn k16a_kernel(int waves, bool pw2, bool pcm16) {
+    if constexpr (k16a_has_fallback(A)) {
+        if (waves != k16a_waves(A)) return k16a_pick<A, 8>(pw2, pcm16);
+    }
+    return k16a_pick<A, k16a_waves(A)>(pw2, pcm16);
+}
 Pow2Fn pow2_kernel(const mfcc_plan* p, bool pcm16) {
     const bool pw2 = p->r.c.power == 2.0f;
-    if (p->small_fft == 320) return p->p2_waves == 16 ? k16a_pick<20, 16>(pw2, pcm16) : k16a_pick<20, 8>(pw2, pcm16);
-    if (p->small_fft == 400) return p->p2_waves == 16 ? k16a_pick<25, 16>(pw2, pcm16) : k16a_pick<25, 8>(pw2, pcm16);
-    if (p->small_fft == 480) return p->p2_waves == 16 ? k16a_pick<30, 16>(pw2, pcm16) : k16a_pick<30, 8>(pw2, pcm16);
-    if (p->small_fft == 640) return p->p2_waves == 12 ? k16a_pick<40, 12>(pw2, pcm16) : k16a_pick<40, 8>(pw2, pcm16);
-    if (p->small_fft == 800) return k16a_pick<50, 8>(pw2, pcm16);
-    if (p->small_fft == 960) return k16a_pick<60, 8>(pw2, pcm16);
+#define MFCC_16A_CASE(A) if (p->small_fft == 16 * A) return k16a_kernel<A>(p->p2_waves, pw2, pcm16);
+    MFCC_16A_LENGTHS(MFCC_16A_CASE)
+#undef MFCC_16A_CASE
     if (p->small_fft == 8) return p->p2_waves == 16 ? pow2_pick<8, 16>(pw2, pcm16) : pow2_pick<8, 8>(pw2, pcm16);
     if (p->small_fft == 9) return p->p2_waves == 16 ? pow2_pick<9, 16>(pw2, pcm16) : pow2_pick<9, 8>(pw2, pcm16);
     return p->p2_waves == 16 ? pow2_pick<10, 16>(pw2, pcm16) : pow2_pick<10, 8>(pw2, pcm16);
@@ -832,9 +840,9 @@ bool build_16a_tables(mfcc_plan* p, const std::vector<float>& basis, std::vector
                         &p->p2_quads, &p->p2_rounds))
         return false;
     p->p2_waves = 0;
-    const char* force = std::getenv("MFCC_HIP_P2_WAVES");      // experiments: 8, 12 (A = 40 only) or 16
-    for (int w : {16, 12, 8})
-        if ((w != 12 || A == 40) && (w != 16 || A < 40) && (!force || std::atoi(force) == w) &&
+    const char* force = std::getenv("MFCC_HIP_P2_WAVES");      // experiments: the length's own count or 8
+    for (int w : {k16a_waves(A), 8})
+        if ((w == k16a_waves(A) || k16a_has_fallback(A)) && (!force || std::atoi(force) == w) &&
             G::lds_bytes(w, p->p2_quads, p->p2_rounds) <= (size_t)k2048::LDS_LIMIT) {
             p->p2_waves = w;
             break;
@@ -1031,17 +1039,15 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
         for (size_t i = 0; i < jobs.size(); ++i)
             jobs[i] = make_int2(4 * p->mj.at[i], 4 * (k2048::MCELL_OFF + p->mj.cell[i]) | (p->mj.cont[i] ? 1 : 0));
     }
-    // n_fft 256 / 320 / 400 / 480 / 512 / 640 / 800 / 960 / 1024: the in-register FFT kernels (MFCC_HIP_DENSE_DFT=1 keeps the dense-DFT one)
+    // n_fft 256 / 512 / 1024 and the 16 A lengths (128 ... 960): the in-register FFT kernels (MFCC_HIP_DENSE_DFT=1 keeps the dense-DFT one)
     std::vector<float2> p2_tw1;
     std::vector<float4> p2_melw;
     std::vector<uint2> p2_pairs;
     if (!std::getenv("MFCC_HIP_DENSE_DFT")) {
-        if (r.c.n_fft == 320 && build_16a_tables<20>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 320;
-        if (r.c.n_fft == 400 && build_16a_tables<25>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 400;
-        if (r.c.n_fft == 480 && build_16a_tables<30>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 480;
-        if (r.c.n_fft == 640 && build_16a_tables<40>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 640;
-        if (r.c.n_fft == 800 && build_16a_tables<50>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 800;
-        if (r.c.n_fft == 960 && build_16a_tables<60>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 960;
+#define MFCC_16A_TABLES(A) \
+        if (r.c.n_fft == 16 * A && build_16a_tables<A>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 16 * A;
+        MFCC_16A_LENGTHS(MFCC_16A_TABLES)
+#undef MFCC_16A_TABLES
         if (r.c.n_fft == 256 && build_pow2_tables<8>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 8;
         if (r.c.n_fft == 512 && build_pow2_tables<9>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 9;
         if (r.c.n_fft == 1024 && build_pow2_tables<10>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 10;
@@ -1215,7 +1221,7 @@ static int launch_front(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
         pa.reflect = plan->r.c.pad_mode == MFCC_PAD_REFLECT;
         pa.pw_mode = plan->r.c.power == 2.0f ? 0 : (plan->r.c.power == 1.0f ? 1 : 2);
         pa.half_power = 0.5f * plan->r.c.power;
-        const int passes_per_tile = plan->small_fft >= 320 ? TILE_FRAMES / k16a::T : (1 << plan->small_fft) / 128;
+        const int passes_per_tile = plan->small_fft > 10 ? TILE_FRAMES / k16a::T : (1 << plan->small_fft) / 128;
         const int64_t wg_needed = (L.ub_tiles * passes_per_tile + plan->p2_waves - 1) / plan->p2_waves;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(wg_needed, plan->n_cu));
         if (ev) HIP_TRY(hipEventRecord(ev[0], st));
@@ -1457,12 +1463,21 @@ int mfcc_workspace_status(const void* d_workspace, void* stream) {
 const char* mfcc_plan_front_kernel(const mfcc_plan* plan) {
     if (!plan) return nullptr;
     if (plan->fast2048) return "fft2048";
-    if (plan->small_fft == 320) return "fft320";
-    if (plan->small_fft == 400) return "fft400";
-    if (plan->small_fft == 480) return "fft480";
-    if (plan->small_fft == 640) return "fft640";
-    if (plan->small_fft == 800) return "fft800";
-    if (plan->small_fft == 960) return "fft960";
+    switch (plan->small_fft) {
+        case 128: return "fft128";
+        case 160: return "fft160";
+        case 192: return "fft192";
+        case 320: return "fft320";
+        case 384: return "fft384";
+        case 400: return "fft400";
+        case 480: return "fft480";
+        case 576: return "fft576";
+        case 640: return "fft640";
+        case 768: return "fft768";
+        case 800: return "fft800";
+        case 960: return "fft960";
+        default: break;
+    }
     if (plan->small_fft == 8) return "fft256";
     if (plan->small_fft == 9) return "fft512";
     if (plan->small_fft == 10) return "fft1024";

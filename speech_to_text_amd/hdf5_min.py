@@ -329,6 +329,50 @@ def write_many_features_native(paths, arrays, attr_rows, name: str = "mfccs") ->
         raise OSError(_lib.lib().mfcc_host_file_error().decode("utf-8", "replace"))
 
 
+def write_feature_batch_native(paths, base: np.ndarray, row_offsets, int_names, int_rows, str_name: str,
+                               strings, name: str = "mfccs", n_threads: int = 1) -> None:
+    """The per-utterance files of one GPU batch in one native call, straight from the batch's host
+    buffer: file i (``paths[i]``) holds rows ``row_offsets[i] : row_offsets[i + 1]`` of the 2-D
+    float32 array ``base`` as dataset ``name``, the int64 attributes ``int_names`` with the values
+    ``int_rows[i]`` and then the string attribute ``str_name`` = ``strings[i]`` -- the order of
+    /root/reference/src/preprocess.py:140-144 when ``int_names`` is (speaker_id, chapter_id,
+    utterance_id, sample_rate) and ``str_name`` is transcript.  ``n_threads`` host threads create
+    the files.  Nothing is sliced or copied per utterance in the interpreter."""
+    import ctypes as C
+
+    from . import _lib
+
+    n = len(paths)
+    if n == 0:
+        return
+    if base.dtype != np.float32 or base.ndim != 2 or not base.flags.c_contiguous:
+        raise ValueError("the batch buffer must be a C-contiguous 2-D float32 array")
+    fo = np.ascontiguousarray(row_offsets, dtype=np.int64)
+    ints = np.ascontiguousarray(int_rows, dtype=np.int64)
+    ni = len(int_names)
+    if fo.shape != (n + 1,) or ints.shape != (n, ni) or len(strings) != n:
+        raise ValueError("one path, one row range, one row of integers and one string per file")
+    if fo[0] < 0 or fo[-1] > base.shape[0] or (np.diff(fo) < 0).any():
+        raise ValueError("row offsets outside the batch buffer")
+    cols = int(base.shape[1])
+    na = ni + 1
+    ptrs = (base.ctypes.data + fo[:-1] * (cols * 4)).astype(np.uint64)
+    rows = np.ascontiguousarray(np.diff(fo))
+    all_ints = np.zeros((n, na), dtype=np.int64)
+    all_ints[:, :ni] = ints
+    strs = [None] * (n * na)
+    strs[ni::na] = [s.encode("utf-8") for s in strings]
+    c_paths = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    c_strs = (C.c_char_p * (n * na))(*strs)
+    c_names = (C.c_char_p * na)(*[k.encode("utf-8") for k in list(int_names) + [str_name]])
+    c_kinds = (C.c_int32 * na)(*([0] * ni + [1]))
+    rc = _lib.lib().mfcc_host_write_feature_files_mt(n, c_paths, name.encode("utf-8"), ptrs.ctypes.data, rows.ctypes.data,
+                                                     cols, na, c_names, c_kinds, all_ints.ctypes.data, c_strs,
+                                                     int(n_threads))
+    if rc != 0:
+        raise OSError(_lib.lib().mfcc_host_file_error().decode("utf-8", "replace"))
+
+
 def write_features(path, data: np.ndarray, attrs: Dict[str, AttrValue], name: str = "mfccs") -> None:
     """Write one dataset ``name`` (float32, C-contiguous, any rank >= 1) with scalar attributes
     (Python int -> int64, str -> variable-length UTF-8) to a new HDF5 file at ``path``."""

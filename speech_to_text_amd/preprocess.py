@@ -213,20 +213,55 @@ class Preprocessor:
             print("Data is empty. Aborted.")
             return 0
         self.out_dir.mkdir(parents=True, exist_ok=True)
+        self.stats = {}
         stream, n_mine, ahead = self._decoded_stream(multiprocess)
         budget = int(self.max_batch_seconds * self.NOMINAL_SR)
-        # One writer thread: per file the writers spend more time in the interpreter (arguments,
-        # byte strings) than in I/O, so more threads only add hand-overs of its lock -- measured
-        # slower with 4 threads than with 1 for all three backends.
         if verbose:
             print(f"Processing audio data... rank {self.rank}/{self.world_size}: "
                   f"{n_mine if n_mine is not None else '?'} utterances, GPU batches of up to "
-                  f"{self.max_batch_seconds:g} s of audio, 1 writer thread")
+                  f"{self.max_batch_seconds:g} s of audio")
+        batches = iter_batches(stream, lambda it: it[0].shape[-1], budget)
+        if self._extract is None and self._native_files():
+            done, n_batches, peak_batch, kept, kept_meta = self._run_overlapped(batches, packed, verbose, n_mine)
+        else:
+            done, n_batches, peak_batch, kept, kept_meta = self._run_simple(batches, packed, verbose, n_mine)
+        if packed:
+            from .sink import write_packed
+
+            metas = [dict(sample_rate=m[0], transcript=m[1], speaker_id=m[2], chapter_id=m[3], utterance_id=m[4])
+                     for m in kept_meta]
+            write_packed(self.out_dir / f"packed_{self.rank:05d}.hdf5", kept, metas, backend=self.hdf5_backend)
+        self.stats.update({"utterances": done, "batches": n_batches, "peak_batch_samples": peak_batch,
+                           "batch_budget_samples": budget,
+                           "decode_calls": ahead.n_fetched if ahead is not None else None,
+                           "peak_decoded_ahead_samples": ahead.peak_ahead if ahead is not None else None})
+        if verbose:
+            print()
+        return done
+
+    def _native_files(self) -> bool:
+        """Whether the per-utterance files come from the writer inside libmfcc_hip.so (no h5py, or
+        ``hdf5_backend='native'``)."""
+        if self.hdf5_backend == "native":
+            return True
+        if self.hdf5_backend is not None:
+            return False
+        try:
+            import h5py  # noqa: F401,WPS433
+        except ImportError:
+            return True
+        return False
+
+    def _run_simple(self, batches, packed, verbose, n_mine):
+        """One batch at a time through ``_features``; a writer thread stores batch k while batch
+        k + 1 is being extracted.  (Injected extractors, h5py and the pure-Python writer.)"""
+        # One writer thread: per file the writers spend more time in the interpreter (arguments,
+        # byte strings) than in I/O, so more threads only add hand-overs of its lock.
         done = n_batches = peak_batch = 0
         kept, kept_meta = [], []
         with ThreadPoolExecutor(max_workers=1) as pool:
             pending = None
-            for _idx, items in iter_batches(stream, lambda it: it[0].shape[-1], budget):
+            for _idx, items in batches:
                 waves = [_waveform_to_numpy(it[0]) for it in items]
                 peak_batch = max(peak_batch, sum(int(w.shape[-1]) for w in waves))
                 feats = self._features(waves)
@@ -246,19 +281,76 @@ class Preprocessor:
                     print(f"Progress: {done}/{n_mine if n_mine is not None else '?'}", end="\r")
             if pending is not None:
                 pending.result()
-        if packed:
-            from .sink import write_packed
+        return done, n_batches, peak_batch, kept, kept_meta
 
-            metas = [dict(sample_rate=m[0], transcript=m[1], speaker_id=m[2], chapter_id=m[3], utterance_id=m[4])
-                     for m in kept_meta]
-            write_packed(self.out_dir / f"packed_{self.rank:05d}.hdf5", kept, metas, backend=self.hdf5_backend)
-        self.stats = {"utterances": done, "batches": n_batches, "peak_batch_samples": peak_batch,
-                      "batch_budget_samples": budget,
-                      "decode_calls": ahead.n_fetched if ahead is not None else None,
-                      "peak_decoded_ahead_samples": ahead.peak_ahead if ahead is not None else None}
-        if verbose:
-            print()
-        return done
+    def _run_overlapped(self, batches, packed, verbose, n_mine):
+        """The GPU path: a staging thread packs and uploads batch k + 1 (pipeline.FeatureStream)
+        while this thread computes batch k and a writer hands batch k - 1's pinned feature buffer to
+        the native file writer, which creates the per-utterance files on several host threads
+        without the interpreter."""
+        import time
+
+        from . import staging
+        from .feature import make_config
+        from .pipeline import features_of_batches
+
+        cfg = make_config(n_fft=self.n_fft, hop_length=self.hop_length, n_mfcc=self.n_mfcc)
+        # file creation is bound by the file system's per-directory lock, not by CPU: two threads
+        # take what there is to take and leave the cores to the packing threads
+        write_threads = int(os.environ.get("MFCC_WRITE_THREADS", "0")) or min(2, staging.host_threads())
+        done = n_batches = peak_batch = 0
+        kept, kept_meta = [], []
+        t_write = [0.0]
+        timeline: dict = {"write": []}
+
+        peak = [0]
+
+        def tagged():
+            for _idx, items in batches:
+                waves = [_waveform_to_numpy(it[0]) for it in items]
+                peak[0] = max(peak[0], sum(int(w.shape[-1]) for w in waves))
+                yield [it[1:] for it in items], waves
+
+        def write(metas, host, fo, release):
+            t0 = time.perf_counter()
+            try:
+                out = os.fspath(self.out_dir)
+                paths = [f"{out}/{m[2]}_{m[3]}_{m[4]}.hdf5" for m in metas]          # feature_file_name
+                ints = [(int(m[2]), int(m[3]), int(m[4]), int(m[0])) for m in metas]
+                hdf5_min.write_feature_batch_native(
+                    paths, host, fo, ("speaker_id", "chapter_id", "utterance_id", "sample_rate"), ints, "transcript",
+                    [str(m[1]) for m in metas], n_threads=write_threads)
+            finally:
+                release()
+                t_write[0] += time.perf_counter() - t0
+                timeline["write"].append((t0, time.perf_counter()))
+
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pending = []
+            for metas, host, fo, release in features_of_batches(tagged(), cfg, self.device,
+                                                                try_int16=self.ingest == "int16", timeline=timeline):
+                if packed:
+                    block = host.copy()
+                    release()
+                    kept.extend(block[int(a):int(b)] for a, b in zip(fo[:-1], fo[1:]))
+                    kept_meta.extend(metas)
+                else:
+                    pending.append(pool.submit(write, metas, host, fo, release))
+                    while len(pending) > 1:
+                        pending.pop(0).result()
+                done += len(metas)
+                n_batches += 1
+                if verbose:
+                    print(f"Progress: {done}/{n_mine if n_mine is not None else '?'}", end="\r")
+            for f in pending:
+                f.result()
+        self.stats["file_writer"] = {"threads": write_threads, "seconds_in_writer": t_write[0]}
+        # seconds each stage was busy, and the wall clock from the first stage call to the last write
+        spans = [x for v in timeline.values() for x in v]
+        self.stats["stage_seconds"] = {k: sum(b - a for a, b in v) for k, v in timeline.items()}
+        self.stats["stage_seconds"]["wall"] = (max(b for _, b in spans) - min(a for a, _ in spans)) if spans else 0.0
+        self.timeline = timeline
+        return done, n_batches, peak[0], kept, kept_meta
 
     def read_preprocessed_data(self):
         """/root/reference/src/preprocess.py:169-176."""

@@ -74,6 +74,24 @@ int main() {
     worst = fmax(worst, check_rdft_even<40>());
     worst = fmax(worst, check_rdft_even<50>());
     worst = fmax(worst, check_rdft_even<60>());
+    worst = fmax(worst, check_rdft_even<8>());
+    worst = fmax(worst, check_rdft_even<10>());
+    worst = fmax(worst, check_rdft_even<12>());
+    worst = fmax(worst, check_rdft_even<24>());
+    worst = fmax(worst, check_rdft_even<36>());
+    worst = fmax(worst, check_rdft_even<48>());
+    worst = fmax(worst, check_rdft_even<62>());
+    // the series behind the trigonometric constants of lengths without a literal table: within
+    // 5e-15 of libm everywhere, and float for float what the literal tables hold
+    for (int A = 2; A <= 64; ++A)
+        for (int j = 0; j < A; ++j) {
+            worst = fmax(worst, fabs(fc::trig_unit(j, A, false) - cos(2 * PI * j / A)) > 5e-15 ? 1.0 : 0.0);
+            worst = fmax(worst, fabs(fc::trig_unit(j, A, true) - sin(2 * PI * j / A)) > 5e-15 ? 1.0 : 0.0);
+        }
+    for (int j = 0; j < 20; ++j)
+        if ((float)fc::trig_unit(j, 20, false) != fc::C20[j] || (float)fc::trig_unit(j, 20, true) != fc::S20[j]) worst = 1.0;
+    for (int j = 0; j < 60; ++j)
+        if ((float)fc::trig_unit(j, 60, false) != fc::C60[j] || (float)fc::trig_unit(j, 60, true) != fc::S60[j]) worst = 1.0;
     worst = fmax(worst, check_rdft_cols<2>());
     worst = fmax(worst, check_rdft_cols<4>());
     worst = fmax(worst, check_rdft_cols<8>());

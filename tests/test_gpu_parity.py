@@ -96,6 +96,12 @@ def test_reference_default_one_utterance(S):
     dict(n_fft=800, hop_length=200, n_mels=80, sr=16000),          # 50 x 16
     dict(n_fft=960, hop_length=480, n_mels=64, sr=48000, pad_mode="reflect"),   # 60 x 16
     dict(n_fft=600, hop_length=150, n_mels=40, sr=16000),          # dense-DFT kernel
+    dict(n_fft=128, hop_length=32, n_mels=20, sr=8000),            # 8 x 16
+    dict(n_fft=160, hop_length=80, n_mels=23, sr=8000, pad_mode="reflect"),     # 10 x 16
+    dict(n_fft=192, hop_length=48, n_mels=32, sr=16000),           # 12 x 16
+    dict(n_fft=384, hop_length=160, n_mels=80, sr=16000),          # 24 x 16
+    dict(n_fft=576, hop_length=144, n_mels=64, sr=22050, pad_mode="reflect"),   # 36 x 16
+    dict(n_fft=768, hop_length=256, n_mels=128, sr=48000),         # 48 x 16
     dict(n_fft=512, hop_length=160, n_mels=10, sr=16000),          # wide filters on the 512-point kernel
     dict(n_fft=1024, hop_length=256, n_mels=256, sr=44100),        # 16 mel rounds of 32 filters
     dict(n_fft=400, hop_length=160, n_mels=1, sr=16000),
@@ -126,6 +132,9 @@ def test_melspectrogram_parity(S, kw):
     dict(n_fft=256, hop_length=80, n_mfcc=13, n_mels=40, sr=8000),
     dict(n_fft=480, hop_length=160, n_mfcc=13, n_mels=80, sr=16000),
     dict(n_fft=320, hop_length=160, n_mfcc=13, n_mels=40, sr=16000),
+    dict(n_fft=384, hop_length=160, n_mfcc=13, n_mels=80, sr=16000),
+    dict(n_fft=768, hop_length=384, n_mfcc=20, n_mels=128, sr=48000),
+    dict(n_fft=160, hop_length=80, n_mfcc=13, n_mels=23, sr=8000),
 ])
 def test_mfcc_parity(S, kw):
     y = speech_like(52001, seed=5)
@@ -136,7 +145,8 @@ def test_mfcc_parity(S, kw):
     np.testing.assert_allclose(got, want, rtol=0, atol=DB_TOL)
 
 
-@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160), (512, 128), (1024, 256), (256, 64), (480, 160), (320, 80), (640, 160), (800, 200), (960, 240)])
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (400, 160), (512, 128), (1024, 256), (256, 64), (480, 160), (320, 80), (640, 160), (800, 200), (960, 240),
+                                       (128, 32), (160, 40), (192, 64), (384, 96), (576, 192), (768, 256)])
 def test_spectrogram_parity(S, n_fft, hop):
     y = speech_like(30000, seed=4)
     want = np.abs(R.stft(y, n_fft=n_fft, hop_length=hop)) ** 2

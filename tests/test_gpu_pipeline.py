@@ -174,10 +174,25 @@ def test_int16_pcm_ingest_is_bit_identical(gpu, kw):
     (dict(n_fft=800, hop_length=320, n_mels=80, sr=32000), "fft800"),
     (dict(n_fft=960, hop_length=480, n_mels=80, sr=48000), "fft960"),
     (dict(n_fft=600, hop_length=150, n_mels=80, sr=16000), "dense_dft"),
+    (dict(n_fft=128, hop_length=64, n_mels=20, sr=8000), "fft128"),
+    (dict(n_fft=160, hop_length=80, n_mels=23, sr=8000), "fft160"),
+    (dict(n_fft=192, hop_length=96, n_mels=32, sr=16000), "fft192"),
+    (dict(n_fft=384, hop_length=160, n_mels=80, sr=16000), "fft384"),
+    (dict(n_fft=576, hop_length=160, n_mels=80, sr=22050), "fft576"),
+    (dict(n_fft=768, hop_length=256, n_mels=128, sr=48000), "fft768"),
+    (dict(n_fft=4096, hop_length=1024), None),
+    (dict(n_fft=2047, hop_length=512), None),
 ])
 def test_front_kernel_selection(gpu, kw, name):
     import speech_to_text_amd as S
 
+    if name is None:       # lengths no kernel takes: refused as unsupported, not as invalid parameters
+        from speech_to_text_amd import _lib
+
+        with pytest.raises(_lib.LibraryError) as e:
+            S.MfccPlan(S.make_config(n_mfcc=13, **kw))
+        assert e.value.code == _lib.MFCC_E_UNSUPPORTED
+        return
     plan = S.MfccPlan(S.make_config(n_mfcc=13, **kw))
     assert plan.front_kernel == name
     plan.close()
@@ -205,6 +220,16 @@ def test_front_kernel_selection(gpu, kw, name):
     dict(n_fft=800, hop_length=333, n_mels=128, n_mfcc=20, sr=32000, pad_mode="reflect", window="hamming"),
     dict(n_fft=960, hop_length=480, n_mels=80, n_mfcc=13, sr=48000),
     dict(n_fft=960, hop_length=960, n_mels=23, n_mfcc=13, sr=16000, center=False, power=1.0),
+    dict(n_fft=128, hop_length=32, n_mels=20, n_mfcc=13, sr=8000),
+    dict(n_fft=128, hop_length=128, n_mels=16, n_mfcc=13, sr=8000, center=False, power=1.0),
+    dict(n_fft=160, hop_length=80, n_mels=23, n_mfcc=13, sr=8000, pad_mode="reflect"),
+    dict(n_fft=192, hop_length=50, n_mels=40, n_mfcc=20, sr=16000, window="hamming"),
+    dict(n_fft=384, hop_length=160, n_mels=80, n_mfcc=13, sr=16000),
+    dict(n_fft=384, hop_length=97, n_mels=128, n_mfcc=20, sr=16000, pad_mode="reflect", window="hamming"),
+    dict(n_fft=576, hop_length=144, n_mels=80, n_mfcc=13, sr=22050),
+    dict(n_fft=576, hop_length=576, n_mels=23, n_mfcc=13, sr=16000, center=False, power=1.0),
+    dict(n_fft=768, hop_length=256, n_mels=128, n_mfcc=20, sr=48000, pad_mode="reflect"),
+    dict(n_fft=768, hop_length=192, n_mels=80, n_mfcc=13, sr=16000, win_length=600),
 ])
 def test_fft_and_dense_dft_kernels_agree(gpu, kw, monkeypatch):
     """The in-register FFT kernel and the dense-DFT kernel are independent implementations of the
@@ -421,3 +446,84 @@ def test_bench_under_torchrun_initialises_rccl(gpu):
     assert st["audio_hours_per_s"] > 0 and len(st["per_rank_seconds"]) == 1
     assert line["rccl"]["ranks_seen"] == 1 and line["rccl"]["cmvn_allreduce_ok"]
     assert line["sustained"]["steps"] >= 5 and line["sustained"]["audio_hours_per_s"] > 0
+
+
+def test_overlapped_batches_match_single_batches(gpu):
+    """pipeline.features_of_batches (a staging thread packing and uploading ahead, the download
+    into pinned slots behind) gives, batch for batch, exactly what mfcc_batch gives for the same
+    utterances -- float32 waveforms, float32 converted to 16-bit PCM while packing, and int16
+    sources; the slots are recycled (more batches than slots), one batch spans several staging
+    chunks, and the features of an utterance match the oracle."""
+    import speech_to_text_amd as S
+    from speech_to_text_amd import pipeline, staging
+
+    lens = ragged_lengths(40, 0.3, 4.0, seed=9)
+    ys = [speech_like(int(n), seed=300 + i, int16_grid=True) for i, n in enumerate(lens)]
+    big = speech_like(staging.CHUNK_BYTES // 4 + 70001, seed=77, int16_grid=True)       # > one chunk of float32
+    batches = [("a", ys[:7]), ("b", [big] + ys[7:9]), ("c", ys[9:10]), ("d", ys[10:25]), ("e", ys[25:26]),
+               ("f", ys[26:]), ("g", [ys[3][:100], ys[4][:1]])]
+    want = {tag: S.mfcc_batch(b, n_fft=2048, hop_length=512, n_mfcc=13) for tag, b in batches}
+    for kind in ("f32", "f32_to_i16", "i16"):
+        src = [(tag, [np.rint(y * 32768.0).astype(np.int16) for y in b] if kind == "i16" else b) for tag, b in batches]
+        with pytest.warns(UserWarning, match="too large for input signal"):
+            got = pipeline.mfcc_of_batches(iter(src), n_fft=2048, hop_length=512, n_mfcc=13, device=gpu,
+                                           try_int16=kind == "f32_to_i16")
+        assert [t for t, _ in got] == [t for t, _ in batches]
+        for tag, feats in got:
+            assert len(feats) == len(want[tag])
+            for a, b in zip(feats, want[tag]):
+                assert a.shape == b.shape and np.array_equal(a, b), (kind, tag)
+    np.testing.assert_allclose(want["a"][2], R.process_audio_features(ys[2]), rtol=0, atol=1e-2)
+
+
+def test_overlapped_batches_report_bad_audio_and_stager_errors(gpu):
+    """A non-finite sample raises ParameterError (librosa's valid_audio) from the batch that holds
+    it; an exception in the iterable that feeds the staging thread reaches the consumer."""
+    import speech_to_text_amd as S
+    from speech_to_text_amd import pipeline
+
+    ys = [speech_like(9000 + 100 * i, seed=i) for i in range(6)]
+    bad = ys[4].copy()
+    bad[17] = np.inf
+    cfg = S.make_config(n_fft=2048, hop_length=512, n_mfcc=13)
+    seen = []
+    with pytest.raises(S.ParameterError, match="not finite"):
+        for tag, host, fo, release in pipeline.features_of_batches([(0, ys[:2]), (1, ys[2:4]), (2, [bad, ys[5]])], cfg, gpu):
+            seen.append(tag)
+            release()
+    assert seen == [0, 1]
+
+    def feed():
+        yield 0, ys[:3]
+        raise KeyError("decode failed")
+
+    with pytest.raises(KeyError, match="decode failed"):
+        for tag, host, fo, release in pipeline.features_of_batches(feed(), cfg, gpu):
+            release()
+    with pytest.raises(S.ParameterError, match="floating-point"):
+        for _ in pipeline.features_of_batches([(0, [np.arange(5000, dtype=np.int32)])], cfg, gpu):
+            pass
+
+
+def test_preprocess_overlapped_files_match_oracle_and_stats(gpu, tmp_path):
+    """Preprocessor.preprocess on the GPU path (several small batches so that staging, compute and
+    the native multi-threaded file writer overlap): every file holds the oracle's features and the
+    reference's attributes, no partial directory is left, and the stage times are reported."""
+    import speech_to_text_amd as S
+
+    lens = ragged_lengths(23, 0.4, 2.5, seed=21)
+    items = [(speech_like(int(n), seed=500 + i, int16_grid=True)[None, :], 16000, f"SENTENCE {i} é", 10 + i, 20 + i % 3, i)
+             for i, n in enumerate(lens)]
+    for ingest in ("float32", "int16"):
+        out = tmp_path / f"mfcc_{ingest}"
+        pre = S.Preprocessor(items, str(out), device=gpu, max_batch_seconds=6.0, ingest=ingest, hdf5_backend="native")
+        assert pre.preprocess(verbose=False) == len(items)
+        assert pre.stats["batches"] >= 5 and pre.stats["stage_seconds"]["wall"] > 0
+        assert not (tmp_path / f"mfcc_{ingest}.partial").exists()
+        assert len(list(out.iterdir())) == len(items)
+        for i, it in enumerate(items):
+            arr, attrs = S.read_feature_file(out / f"{it[3]}_{it[4]}_{it[5]}.hdf5")
+            assert attrs == dict(speaker_id=it[3], chapter_id=it[4], utterance_id=it[5], sample_rate=16000, transcript=it[2])
+            assert list(attrs) == ["speaker_id", "chapter_id", "utterance_id", "sample_rate", "transcript"]
+            if i % 5 == 0:
+                np.testing.assert_allclose(arr, R.process_audio_features(it[0][0]), rtol=0, atol=1e-2)

@@ -370,3 +370,81 @@ def test_decode_ahead_never_loses_the_last_chunk(monkeypatch):
         da = DecodeAhead(lambda i: np.full(3, i), range(n), size_of=len, workers=workers, chunk=chunk)
         seen = sorted(i for i, r in da if int(r[0]) == i)
         assert seen == list(range(n)), (n, workers, chunk, seen)
+
+
+def test_native_batch_file_writer_from_one_buffer(tmp_path):
+    """mfcc_host_write_feature_files_mt through hdf5_min.write_feature_batch_native: the files of a
+    batch written from the batch's one host buffer on several threads are byte for byte the files
+    the one-file writer makes (the schema of /root/reference/src/preprocess.py:138-144, attributes
+    in that order), an empty utterance and non-ASCII transcripts included; a bad directory is an
+    OSError and leaves no partial directory behind."""
+    from speech_to_text_amd import hdf5_min
+
+    rng = np.random.default_rng(11)
+    rows = [5, 0, 130, 1, 77, 300, 2, 9]
+    fo = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    base = rng.random((int(fo[-1]) + 4, 13), dtype=np.float32)        # the buffer may be larger than the batch
+    metas = [(16000, f"TEXT {i} é✓", 100 + i, 2000 + i, i) for i in range(len(rows))]
+    for threads in (1, 4):
+        out = tmp_path / f"mfcc{threads}"
+        out.mkdir()
+        paths = [f"{out}/{m[2]}_{m[3]}_{m[4]}.hdf5" for m in metas]
+        hdf5_min.write_feature_batch_native(paths, base, fo, ("speaker_id", "chapter_id", "utterance_id", "sample_rate"),
+                                            [(m[2], m[3], m[4], m[0]) for m in metas], "transcript",
+                                            [m[1] for m in metas], n_threads=threads)
+        assert sorted(p.name for p in out.iterdir()) == sorted(Path(p).name for p in paths)
+        assert not (tmp_path / f"mfcc{threads}.partial").exists()
+        for i, m in enumerate(metas):
+            one = tmp_path / "one.hdf5"
+            hdf5_min.write_features(one, base[fo[i]:fo[i + 1]],
+                                    dict(speaker_id=m[2], chapter_id=m[3], utterance_id=m[4], sample_rate=m[0], transcript=m[1]))
+            assert Path(paths[i]).read_bytes() == one.read_bytes()
+    with pytest.raises(OSError):
+        hdf5_min.write_feature_batch_native([str(tmp_path / "nowhere" / "a.hdf5")], base, fo[:2], ("speaker_id",), [(1,)],
+                                            "transcript", ["x"], n_threads=2)
+    with pytest.raises(ValueError):
+        hdf5_min.write_feature_batch_native(["a"], base[:, ::2], fo[:2], ("speaker_id",), [(1,)], "transcript", ["x"])
+    with pytest.raises(ValueError):
+        hdf5_min.write_feature_batch_native(["a"], base, np.array([0, 10 ** 9]), ("speaker_id",), [(1,)], "transcript", ["x"])
+
+
+def test_native_pack_range_matches_concatenation():
+    """mfcc_host_pack_range: any sub-range [a, b) of the concatenation of ragged utterances (empty
+    ones included) lands where numpy's concatenate puts it, for float32, int16 and float32 -> int16;
+    a sample off the int16 grid is reported (0), not converted."""
+    from speech_to_text_amd import _lib
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(3)
+    lens = [7, 0, 1000, 1, 0, 333, 4096, 5]
+    so = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    f32 = [(rng.integers(-32768, 32768, n).astype(np.float32) / np.float32(32768.0)) for n in lens]
+    i16 = [np.rint(x * 32768.0).astype(np.int16) for x in f32]
+    total = int(so[-1])
+    for mode, src, want, dt in ((0, f32, np.concatenate(f32), np.float32), (1, i16, np.concatenate(i16), np.int16),
+                                (2, f32, np.concatenate(i16), np.int16)):
+        ptrs = np.array([x.__array_interface__["data"][0] for x in src], dtype=np.uint64)
+        for c0, a, b in ((0, 0, total), (0, 5, 9), (6, 7, 1008), (1000, 1007, 1007), (7, 1007, total), (100, 1500, 5441)):
+            dst = np.full(total - c0 + 3, 77, dtype=dt)
+            rc = lib.mfcc_host_pack_range(ptrs.ctypes.data, so.ctypes.data, len(lens), dst.ctypes.data, c0, a, b, mode)
+            assert rc == 1
+            assert np.array_equal(dst[a - c0:b - c0], want[a:b])
+            assert (dst[:a - c0] == 77).all() and (dst[b - c0:] == 77).all()
+    bad = [x.copy() for x in f32]
+    bad[2][500] += np.float32(1e-6)
+    ptrs = np.array([x.__array_interface__["data"][0] for x in bad], dtype=np.uint64)
+    dst = np.zeros(total, dtype=np.int16)
+    assert lib.mfcc_host_pack_range(ptrs.ctypes.data, so.ctypes.data, len(lens), dst.ctypes.data, 0, 0, total, 2) == 0
+    assert lib.mfcc_host_pack_range(ptrs.ctypes.data, so.ctypes.data, len(lens), dst.ctypes.data, 0, 0, 400, 2) == 1
+    assert lib.mfcc_host_pack_range(ptrs.ctypes.data, so.ctypes.data, len(lens), dst.ctypes.data, 10, 5, 20, 0) < 0
+
+
+def test_host_threads_respects_the_jobs_share(monkeypatch):
+    from speech_to_text_amd import staging
+
+    monkeypatch.setenv("OMP_NUM_THREADS", "4")
+    assert staging.host_threads() == 3
+    monkeypatch.setenv("OMP_NUM_THREADS", "1")
+    assert staging.host_threads() == 1
+    monkeypatch.delenv("OMP_NUM_THREADS")
+    assert 1 <= staging.host_threads(5) <= 5
