@@ -1,5 +1,5 @@
 // Issue rate of wave64 VALU instructions on gfx950: v_fma_f32, v_pk_fma_f32, v_pk_add_f32,
-// v_pk_mul_f32, v_mov_b32, v_fmac_f32_dpp, v_add_f32, v_cndmask_b32, v_mov_b32_dpp.  Prints SIMD
+// v_pk_mul_f32, v_mov_b32, v_fmac_f32_dpp, v_add_f32, v_cndmask_b32, v_mov_b32_dpp, v_permlane*_swap.  Prints SIMD
 // cycles per instruction in SHADER clocks: the kernel's duration is taken from the shader-clock
 // counter (s_memtime) of one wavefront, not from wall time and a nominal frequency -- the chip
 // lowers its clock under a dense VALU load.
@@ -45,6 +45,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float s, long lo
                 if (MODE == 23) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
                 if (MODE == 24) asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
                 if (MODE == 25) asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+                if (MODE == 26) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]));
+                if (MODE == 27) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]));
                 if (MODE == 8) asm volatile("v_cndmask_b32_e64 %0, %0, -%1, %2" : "+v"(a[i]) : "v"(s), "s"(msk));
                 if (MODE == 9) asm volatile("v_mov_b32_dpp %0, %1 row_shr:4 row_mask:0xf bank_mask:0x2" : "+v"(a[i]) : "v"(s));
             }
@@ -96,6 +98,7 @@ int main() {
         run<16>("v_sub_f32_e32", d, w); run<17>("v_fma a,sgpr,-b", d, w); run<18>("v_cndmask_e32 vcc", d, w);
         run<19>("v_fma b,c,a", d, w); run<20>("v_mul literal", d, w); run<21>("v_fmac literal", d, w);
         run<22>("v_fma b,c,-a", d, w); run<23>("v_fmac b,c", d, w); run<24>("v_add b,c", d, w); run<25>("v_fma -b,c,a", d, w);
+        run<26>("v_permlane32_swap", d, w); run<27>("v_permlane16_swap", d, w);
     }
     return 0;
 }
