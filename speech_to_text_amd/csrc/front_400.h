@@ -180,9 +180,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_melspec_16a(const Pow2Args a) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) x[i] = pp[16 * i];
             }
+        } else if (!(a.reflect && a.pad) && tc.T > 0) {
+            // a pass with edge frames or fewer than four frames, under zero padding: the same loads
+            // from addresses clamped into the utterance; lanes that fell outside it, and the lanes
+            // of frames past the utterance's last, take 0
+            const int f0 = first + tf * a.hop + b, last = tc.T - 1;
+            if (PCM16) {
+                const int16_t* pp = static_cast<const int16_t*>(a.pcm) + tc.soff;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) x[i] = PCM16_SCALE * (float)pp[min(max(f0 + 16 * i, 0), last)];
+            } else {
+                const float* pp = static_cast<const float*>(a.pcm) + tc.soff;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) x[i] = pp[min(max(f0 + 16 * i, 0), last)];
+            }
+            const bool live = tf < nvalid;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) x[i] = (live && (unsigned)(f0 + 16 * i) <= (unsigned)last) ? x[i] : 0.0f;
         } else {
-            // a pass with edge frames (overlapping the padding or the utterance's end) or with
-            // fewer than four frames: frame by frame through LDS
+            // such a pass under reflect padding: frame by frame through LDS
 #pragma unroll
             for (int i = 0; i < NA; ++i) x[i] = 0.0f;
 #pragma unroll 1

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <string>
 #include <thread>
 #include <vector>
@@ -240,7 +241,10 @@ int write_one(const char* path, const char* dataset_name, const float* h_data, i
         tmp = side + "/" + full.substr(full.find_last_of('/') + 1) + "." + std::to_string((long)::getpid());
     }
     int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
-    if (fd < 0 && !side.empty()) {          // another writer removed the (then empty) side directory meanwhile
+    // Another writer (a thread of this batch, or another rank that shares the directory) may have
+    // removed the side directory while it was empty: make it again and retry, a few times in case
+    // the two keep crossing.
+    for (int attempt = 0; fd < 0 && !side.empty() && errno == ENOENT && attempt < 16; ++attempt) {
         (void)::mkdir(side.c_str(), 0777);
         fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
     }
