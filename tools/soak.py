@@ -157,17 +157,20 @@ def soak(seconds: float, seed: int, max_batches: int = 0, lengths=None):
                             if e_u > err_short:
                                 err_short, worst_short = e_u, (u, L)
             # Against the oracle such line spectra meet 1e-2 dB wherever a band lies within about
-            # 65 dB of the utterance's peak; in the last 15 dB above the top_db floor float32's error
-            # (relative to the frame's energy, not to the band) reaches a few hundredths of a dB --
-            # 3.7e-2 dB is the largest seen (n_fft 576 at sr 8000, 80 mel bands of one bin each, an
-            # utterance of ONE sample).  They are held to 5e-2 dB; everything else to 1e-2 dB.
-            err = max(float(d[~short].max()) if (~short).any() else 0.0, err_short / 5.0)
+            # 65 dB of the utterance's peak.  Below that float32's error shows: it is relative to the
+            # frame's peak (eps ~ 7e-7 of its amplitude for these transforms), not to the band, so a
+            # band `depth` dB down is off by about 8.7 eps 10^(depth / 20) dB -- 0.006 dB at 60 dB,
+            # 0.06 dB at the top_db floor of 80 dB.  Largest seen: 6.5e-2 dB (n_fft 640 at sr 8000,
+            # 128 mel bands of a bin or less each, an utterance of ONE sample).  They are held to
+            # 0.1 dB; everything else to 1e-2 dB.
+            err = max(float(d[~short].max()) if (~short).any() else 0.0, err_short / 10.0)
         else:
             u = int(rng.integers(0, n_utts))
             want = R.mfcc(y=ys[u], **kw).T
             err = float(np.abs(a[int(fo[u]):int(fo[u + 1])] - want).max())
-            if kw["pad_mode"] == "reflect" and lens[u] < n_fft and kw.get("power", 2.0) < 2.0:
-                err = 0.0       # a line spectrum under power < 2: see the note on float32's resolution above
+            if kw["pad_mode"] == "reflect" and lens[u] < n_fft:
+                # a line spectrum: not comparable under power < 2, held to 0.1 dB otherwise (see above)
+                err = 0.0 if kw.get("power", 2.0) < 2.0 else err / 10.0
         gain = 1.0 if kw.get("norm", "ortho") == "ortho" else 2.0 * np.sqrt(kw["n_mels"])   # unnormalised DCT
         gain *= 1.0 + 0.5 * kw.get("lifter", 0)
         err /= gain
