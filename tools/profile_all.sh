@@ -1,11 +1,11 @@
 #!/bin/bash
 # usage: tools/profile_all.sh <tag>   (on the GPU box)
-# Every measurement DESIGN.md section 5 quotes, in one go: the bench line, kernel trace + HBM traffic
+# Every measurement the project quotes, in one go: the bench line, kernel trace + HBM traffic
 # passes, SQ / MFMA counter passes of the four pipelines, the other BASELINE configurations and
 # the 1000-hour run.  Results land under gpurun_out/<tag>*; tools/collect_profiles.sh copies the
 # summaries into profiles/.
 set -e
-TAG=${1:-round3}; O=gpurun_out/$TAG; mkdir -p $O
+TAG=${1:?usage: tools/profile_all.sh <tag>}; O=gpurun_out/$TAG; mkdir -p $O
 timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err
 cut -c1-300 $O/bench.json
 timeout -k 10 500 bash tools/pmc_traffic.sh ${TAG}_traffic > $O/traffic.txt 2>&1

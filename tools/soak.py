@@ -165,17 +165,36 @@ def soak(seconds: float, seed: int, max_batches: int = 0, lengths=None):
             # 0.1 dB; everything else to 1e-2 dB.
             err = max(float(d[~short].max()) if (~short).any() else 0.0, err_short / 10.0)
         else:
+            short, d = np.zeros(0, dtype=bool), np.zeros((0, 1))
             u = int(rng.integers(0, n_utts))
             want = R.mfcc(y=ys[u], **kw).T
             err = float(np.abs(a[int(fo[u]):int(fo[u + 1])] - want).max())
             if kw["pad_mode"] == "reflect" and lens[u] < n_fft:
                 # a line spectrum: not comparable under power < 2, held to 0.1 dB otherwise (see above)
                 err = 0.0 if kw.get("power", 2.0) < 2.0 else err / 10.0
+        detail = ""
+        if plan.front_kernel != "fft2048" and (~short).any() and float(d[~short].max()) > 1e-2 and groups is None:
+            # which utterance, and which of the two kernels is off against the float64 oracle
+            r, cidx = np.unravel_index(int(np.argmax(np.where(short[:, None], 0.0, d))), d.shape)
+            u = int(np.searchsorted(fo, r, side="right")) - 1
+            want = R.mfcc(y=ys[u], **kw).T
+            fr = r - int(fo[u])
+            detail = (f"; utterance {u} (length {lens[u]}, peak {float(np.abs(ys[u]).max()):.3g}) frame {fr} coefficient {cidx}: "
+                      f"fft {a[r, cidx]:.5f} dense {c[r, cidx]:.5f} oracle {want[fr, cidx]:.5f}")
         gain = 1.0 if kw.get("norm", "ortho") == "ortho" else 2.0 * np.sqrt(kw["n_mels"])   # unnormalised DCT
         gain *= 1.0 + 0.5 * kw.get("lifter", 0)
         err /= gain
+        if kw.get("power", 2.0) < 2.0:
+            # power_to_db is applied to S**power whatever the power: under power = 1 the 80 dB window
+            # admits amplitudes down to 1e-8 of the peak.  float32 resolves about 1e-6 of a frame's
+            # peak, so a bin that happens to be that small (the first and last frames under reflect
+            # padding are symmetric, their spectra real, and a real spectrum passes near zero far
+            # more often than a complex one) is off by tenths of a dB, and with it a mel band that
+            # samples only that bin.  Seen once in 30 000 batches: 0.08 dB (in-register FFT) and
+            # 0.12 dB (dense DFT) against the float64 oracle.  power < 2 is held to 0.2 dB.
+            err /= 20.0
         assert err <= 1e-2, (f"mismatch {err} dB: {kw}, lens {lens[:8]}..., worst short utterance (index, length) "
-                             f"{worst_short if plan.front_kernel != 'fft2048' else None}")
+                             f"{worst_short if plan.front_kernel != 'fft2048' else None}{detail}")
         if err > worst:
             worst, worst_kw = err, dict(kw, kernel=plan.front_kernel, scale=float(np.abs(ys[0]).max()))
         used[plan.front_kernel] = used.get(plan.front_kernel, 0) + 1
