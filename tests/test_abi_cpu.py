@@ -164,3 +164,32 @@ def test_odd_n_fft_is_unsupported_not_invalid():
         rc = lib.mfcc_plan_create(C.byref(c), C.byref(handle))
         assert rc == _lib.MFCC_E_UNSUPPORTED and not handle.value
         assert "odd n_fft" in _lib.last_error()
+
+
+def test_header_is_plain_c_and_host_entry_points_work_from_c(tmp_path):
+    """include/mfcc_hip.h compiles as C99 on its own, and a C program linked against the library
+    gets the documented behaviour from the host-only entry points (layout, packing, file writer);
+    the files it writes are the ones the Python reader expects."""
+    import shutil
+    import subprocess
+
+    from speech_to_text_amd import _lib, hdf5_min
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = Path(__file__).resolve().parent.parent
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", str(root / "include" / "mfcc_hip.h")],
+                   check=True)
+    lib = _lib.library_path()
+    exe = tmp_path / "test_c_abi"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", str(root / "include"), str(root / "tests" / "csrc" / "test_c_abi.c"),
+                    str(lib), "-Wl,--allow-shlib-undefined", f"-Wl,-rpath,{lib.parent}", "-o", str(exe)], check=True)
+    out = tmp_path / "mfcc"
+    out.mkdir()
+    r = subprocess.run([str(exe), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and "c_abi_ok" in r.stdout, r.stdout + r.stderr
+    arr, attrs = hdf5_min.read_features(out / "10_20_1.hdf5", "mfccs")
+    assert arr.shape == (3, 13) and arr[0, 0] == 13.0
+    assert attrs == dict(speaker_id=10, chapter_id=20, utterance_id=1, sample_rate=16000, transcript="SECOND")
+    assert not (tmp_path / "mfcc.partial").exists()
