@@ -251,3 +251,38 @@ def test_stft_reflect_tail_slice_shorter_than_the_padding(n_fft, hop, around):
     assert np.array_equal(got[:, :tail_k], whole[:, :tail_k])
     d = np.abs(got[:, tail_k:] - whole[:, tail_k:]).max() / np.abs(whole[:, tail_k:]).max()
     assert d < 1e-4
+
+
+@pytest.mark.parametrize("n_fft,hop,n_mels,sr,pad_mode", [
+    (2048, 512, 128, 22050, "constant"),      # the reference's call, /root/reference/src/preprocess.py:134
+    (2048, 512, 128, 22050, "reflect"),
+    (400, 160, 80, 16000, "constant"),
+    (512, 160, 40, 16000, "reflect"),
+    (1024, 256, 64, 8000, "constant"),
+])
+def test_oracle_agrees_with_an_independent_librosa_compatible_implementation(n_fft, hop, n_mels, sr, pad_mode):
+    """librosa itself is not installed, but Hugging Face transformers ships `audio_utils`, a separate
+    re-implementation of librosa's Slaney mel filterbank, STFT and power_to_db (written to match
+    librosa for the Whisper-style feature extractors).  The oracle and that implementation agree on
+    the filterbank to float32 rounding, on the log-mel spectrogram to 1e-4 dB and on the MFCCs to
+    1e-3 dB -- a third-party witness for the restatement, edge frames of both pad modes included."""
+    A = pytest.importorskip("transformers.audio_utils")
+    import scipy.fftpack
+
+    y = speech_like(60000, seed=12, int16_grid=True)
+    fb = A.mel_filter_bank(1 + n_fft // 2, n_mels, 0.0, sr / 2, sr, norm="slaney", mel_scale="slaney")
+    ours = R.mel(sr=sr, n_fft=n_fft, n_mels=n_mels)
+    assert fb.T.shape == ours.shape
+    assert np.abs(fb.T - ours).max() <= 2e-7 * ours.max()
+    spec = A.spectrogram(y, A.window_function(n_fft, "hann", periodic=True), frame_length=n_fft, hop_length=hop,
+                         fft_length=n_fft, power=2.0, center=True, pad_mode=pad_mode, mel_filters=fb, mel_floor=0.0,
+                         log_mel="dB", reference=1.0, min_value=1e-10, db_range=80.0, dtype=np.float64)
+    want = R.power_to_db(R.melspectrogram(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, pad_mode=pad_mode))
+    assert spec.shape == want.shape
+    assert np.abs(spec - want).max() <= 1e-4
+    # the edge frames are where the pad modes differ: check them on their own
+    edge = max(1, n_fft // 2 // hop + 1)
+    assert np.abs(spec[:, :edge] - want[:, :edge]).max() <= 1e-4 and np.abs(spec[:, -edge:] - want[:, -edge:]).max() <= 1e-4
+    m_other = scipy.fftpack.dct(spec, axis=-2, type=2, norm="ortho")[:13]
+    m_ours = R.mfcc(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, n_mfcc=13, pad_mode=pad_mode)
+    assert np.abs(m_other - m_ours).max() <= 1e-3
