@@ -348,7 +348,13 @@ int mfcc_host_write_feature_files_mt(int32_t n_files, const char* const* paths, 
     } else {
         std::vector<std::thread> pool;
         pool.reserve(T - 1);
-        for (int t = 1; t < T; ++t) pool.emplace_back(work);
+        for (int t = 1; t < T; ++t) {
+            try {
+                pool.emplace_back(work);
+            } catch (...) {          // no more threads to be had: the ones running share the files
+                break;
+            }
+        }
         work();
         for (std::thread& th : pool) th.join();
     }
