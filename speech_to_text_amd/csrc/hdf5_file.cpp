@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -276,6 +277,16 @@ int write_one(const char* path, const char* dataset_name, const float* h_data, i
 
 }  // namespace
 
+// No C++ exception may cross the C ABI.
+#define MFCC_FILE_CATCH_ALL                                                  \
+    catch (const std::bad_alloc&) {                                          \
+        try { g_file_err = "out of host memory"; } catch (...) {}            \
+        return MFCC_E_NOMEM;                                                 \
+    } catch (...) {                                                          \
+        try { g_file_err = "unexpected C++ exception"; } catch (...) {}      \
+        return MFCC_E_INVALID;                                               \
+    }
+
 extern "C" {
 
 const char* mfcc_host_file_error(void) { return g_file_err.c_str(); }
@@ -283,23 +294,23 @@ const char* mfcc_host_file_error(void) { return g_file_err.c_str(); }
 int mfcc_host_write_feature_file(const char* path, const char* dataset_name, const float* h_data, int64_t rows,
                                  int64_t cols, int32_t n_attrs, const char* const* attr_names,
                                  const int32_t* attr_is_string, const int64_t* attr_ints,
-                                 const char* const* attr_strings) {
+                                 const char* const* attr_strings) try {
     return write_one(path, dataset_name, h_data, rows, cols, n_attrs, attr_names, attr_is_string, attr_ints,
                      attr_strings, false);
-}
+} MFCC_FILE_CATCH_ALL
 
 int mfcc_host_write_feature_files(int32_t n_files, const char* const* paths, const char* dataset_name,
                                   const float* const* h_data, const int64_t* rows, int64_t cols, int32_t n_attrs,
                                   const char* const* attr_names, const int32_t* attr_is_string,
-                                  const int64_t* attr_ints, const char* const* attr_strings) {
+                                  const int64_t* attr_ints, const char* const* attr_strings) try {
     return mfcc_host_write_feature_files_mt(n_files, paths, dataset_name, h_data, rows, cols, n_attrs, attr_names,
                                             attr_is_string, attr_ints, attr_strings, 1);
-}
+} MFCC_FILE_CATCH_ALL
 
 int mfcc_host_write_feature_files_mt(int32_t n_files, const char* const* paths, const char* dataset_name,
                                      const float* const* h_data, const int64_t* rows, int64_t cols, int32_t n_attrs,
                                      const char* const* attr_names, const int32_t* attr_is_string,
-                                     const int64_t* attr_ints, const char* const* attr_strings, int32_t n_threads) {
+                                     const int64_t* attr_ints, const char* const* attr_strings, int32_t n_threads) try {
     if (n_files < 0 || (n_files > 0 && (!paths || !h_data || !rows))) {
         g_file_err = "bad arguments";
         return MFCC_E_INVALID;
@@ -364,7 +375,7 @@ int mfcc_host_write_feature_files_mt(int32_t n_files, const char* const* paths, 
         return status.load();
     }
     return MFCC_OK;
-}
+} MFCC_FILE_CATCH_ALL
 
 /* Packs the samples [a, b) of the concatenation of n_utts host utterances (srcs[u] holds
  * offsets[u+1] - offsets[u] elements) into dst[a - c0 ...].  mode 0: float32 -> float32,

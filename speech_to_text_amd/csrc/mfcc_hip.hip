@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -881,6 +882,17 @@ int setup_generic(mfcc_plan* p) {
 
 }  // namespace
 
+// No C++ exception may cross the C ABI: every entry point that can allocate host memory (tables,
+// error strings) is a function-try-block that ends in this handler.
+#define MFCC_CATCH_ALL                                                       \
+    catch (const std::bad_alloc&) {                                          \
+        try { g_err = "out of host memory"; } catch (...) {}                 \
+        return MFCC_E_NOMEM;                                                 \
+    } catch (...) {                                                          \
+        try { g_err = "unexpected C++ exception"; } catch (...) {}           \
+        return MFCC_E_INVALID;                                               \
+    }
+
 extern "C" {
 
 void mfcc_config_default(mfcc_config* c) {
@@ -900,7 +912,7 @@ int mfcc_abi_version(void) { return MFCC_ABI_VERSION; }
 
 const char* mfcc_last_error(void) { return g_err.c_str(); }
 
-int mfcc_host_window(const mfcc_config* cfg, double* h_out) {
+int mfcc_host_window(const mfcc_config* cfg, double* h_out) try {
     mfcc_host::Resolved r;
     const std::string e = mfcc_host::resolve(cfg, &r);
     if (!e.empty()) return fail(MFCC_E_INVALID, e);
@@ -909,9 +921,9 @@ int mfcc_host_window(const mfcc_config* cfg, double* h_out) {
     mfcc_host::build_window(r, w);
     std::memcpy(h_out, w.data(), w.size() * sizeof(double));
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
-int mfcc_host_mel_basis(const mfcc_config* cfg, float* h_out) {
+int mfcc_host_mel_basis(const mfcc_config* cfg, float* h_out) try {
     mfcc_host::Resolved r;
     const std::string e = mfcc_host::resolve(cfg, &r);
     if (!e.empty()) return fail(MFCC_E_INVALID, e);
@@ -920,9 +932,9 @@ int mfcc_host_mel_basis(const mfcc_config* cfg, float* h_out) {
     mfcc_host::build_mel_basis(r, m);
     std::memcpy(h_out, m.data(), m.size() * sizeof(float));
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
-int mfcc_host_dct_basis(const mfcc_config* cfg, float* h_out) {
+int mfcc_host_dct_basis(const mfcc_config* cfg, float* h_out) try {
     mfcc_host::Resolved r;
     const std::string e = mfcc_host::resolve(cfg, &r);
     if (!e.empty()) return fail(MFCC_E_INVALID, e);
@@ -931,7 +943,7 @@ int mfcc_host_dct_basis(const mfcc_config* cfg, float* h_out) {
     mfcc_host::build_dct_basis(r, d);
     std::memcpy(h_out, d.data(), d.size() * sizeof(float));
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
 int64_t mfcc_num_frames(const mfcc_config* cfg, int64_t n_samples) {
     mfcc_host::Resolved r;
@@ -943,7 +955,7 @@ int64_t mfcc_num_frames(const mfcc_config* cfg, int64_t n_samples) {
 }
 
 int mfcc_batch_layout(const mfcc_config* cfg, const int64_t* h_sample_offsets, int32_t n_utts,
-                      int64_t* h_frame_offsets) {
+                      int64_t* h_frame_offsets) try {
     mfcc_host::Resolved r;
     const std::string e = mfcc_host::resolve(cfg, &r);
     if (!e.empty()) return fail(MFCC_E_INVALID, e);
@@ -964,9 +976,9 @@ int mfcc_batch_layout(const mfcc_config* cfg, const int64_t* h_sample_offsets, i
         h_frame_offsets[u + 1] = h_frame_offsets[u] + F;
     }
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
-int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
+int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) try {
     if (!out_plan) return fail(MFCC_E_INVALID, "out_plan is NULL");
     *out_plan = nullptr;
     // librosa computes an odd-length transform; this library has no kernel for one -- a limit of
@@ -1148,7 +1160,7 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) {
     }
     *out_plan = p;
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
 void mfcc_plan_destroy(mfcc_plan* p) {
     if (!p) return;
@@ -1365,22 +1377,22 @@ static int execute_impl(const mfcc_plan* plan, const void* d_pcm, bool pcm16, co
 int mfcc_execute(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sample_offsets,
                  const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
                  int64_t total_frames, float* d_out, float* d_melspec_out, void* d_workspace,
-                 size_t workspace_bytes, void* stream) {
+                 size_t workspace_bytes, void* stream) try {
     return execute_impl(plan, d_pcm, false, d_sample_offsets, d_frame_offsets, d_group, n_utts, total_frames,
                         d_out, d_melspec_out, d_workspace, workspace_bytes, stream);
-}
+} MFCC_CATCH_ALL
 
 int mfcc_execute_pcm16(const mfcc_plan* plan, const int16_t* d_pcm16, const int64_t* d_sample_offsets,
                        const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
                        int64_t total_frames, float* d_out, float* d_melspec_out, void* d_workspace,
-                       size_t workspace_bytes, void* stream) {
+                       size_t workspace_bytes, void* stream) try {
     return execute_impl(plan, d_pcm16, true, d_sample_offsets, d_frame_offsets, d_group, n_utts, total_frames,
                         d_out, d_melspec_out, d_workspace, workspace_bytes, stream);
-}
+} MFCC_CATCH_ALL
 
 int mfcc_execute_noalloc(const mfcc_plan* plan, const float* d_pcm, const int64_t* d_sample_offsets,
                          const int64_t* d_frame_offsets, const int32_t* d_group, int32_t n_utts,
-                         int64_t total_frames, float* d_out, void* stream) {
+                         int64_t total_frames, float* d_out, void* stream) try {
     if (!plan) return fail(MFCC_E_INVALID, "plan is NULL");
     if (n_utts < 0 || total_frames < 0) return fail(MFCC_E_INVALID, "negative batch size");
     int dev = -1;
@@ -1395,9 +1407,9 @@ int mfcc_execute_noalloc(const mfcc_plan* plan, const float* d_pcm, const int64_
                                       ": split the batch or call mfcc_execute with a workspace of your own");
     return execute_impl(plan, d_pcm, false, d_sample_offsets, d_frame_offsets, d_group, n_utts, total_frames, d_out,
                         nullptr, plan->static_scratch, (size_t)MFCC_NOALLOC_SCRATCH_BYTES, stream);
-}
+} MFCC_CATCH_ALL
 
-int mfcc_plan_set_profiling(mfcc_plan* plan, int enable) {
+int mfcc_plan_set_profiling(mfcc_plan* plan, int enable) try {
     if (!plan) return fail(MFCC_E_INVALID, "plan is NULL");
     // (switching profiling on or off is for a quiet plan: no execute of it may be in flight on
     // another thread; the executes themselves may then run concurrently)
@@ -1413,9 +1425,9 @@ int mfcc_plan_set_profiling(mfcc_plan* plan, int enable) {
     if (plan->ev_done)
         for (int i = 0; i < mfcc_plan::EV_RING; ++i) plan->ev_done[i].store(0);
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
-int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_dct) {
+int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_dct) try {
     if (!plan || !plan->ev_ring) return fail(MFCC_E_INVALID, "profiling was not enabled on this plan");
     const int64_t count = plan->ev_count.load();
     if (count == 0) return fail(MFCC_E_INVALID, "no execute has been recorded since profiling was enabled");
@@ -1427,9 +1439,9 @@ int mfcc_plan_last_timings(const mfcc_plan* plan, float* ms_front, float* ms_db_
     if (ms_front) HIP_TRY(hipEventElapsedTime(ms_front, ev[0], ev[1]));
     if (ms_db_dct) HIP_TRY(hipEventElapsedTime(ms_db_dct, ev[1], ev[2]));
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
-int mfcc_plan_timing_history(const mfcc_plan* plan, int32_t max_n, float* ms_front, float* ms_db_dct) {
+int mfcc_plan_timing_history(const mfcc_plan* plan, int32_t max_n, float* ms_front, float* ms_db_dct) try {
     if (!plan || !plan->ev_ring) return fail(MFCC_E_INVALID, "profiling was not enabled on this plan");
     if (max_n < 0) return fail(MFCC_E_INVALID, "max_n is negative");
     const int64_t count = plan->ev_count.load();
@@ -1447,9 +1459,9 @@ int mfcc_plan_timing_history(const mfcc_plan* plan, int32_t max_n, float* ms_fro
         ++got;
     }
     return got;
-}
+} MFCC_CATCH_ALL
 
-int mfcc_workspace_status(const void* d_workspace, void* stream) {
+int mfcc_workspace_status(const void* d_workspace, void* stream) try {
     if (!d_workspace) return fail(MFCC_E_INVALID, "d_workspace is NULL");
     WsHeader h;
     HIP_TRY(hipMemcpyAsync(&h, d_workspace, sizeof(h), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
@@ -1458,7 +1470,7 @@ int mfcc_workspace_status(const void* d_workspace, void* stream) {
         return fail(MFCC_E_INVALID, std::to_string(h.bad_groups) + " utterance(s) had a d_group value outside "
                                     "[0, n_utts); each was given a top_db maximum of its own");
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
 const char* mfcc_plan_front_kernel(const mfcc_plan* plan) {
     if (!plan) return nullptr;
@@ -1487,7 +1499,7 @@ const char* mfcc_plan_front_kernel(const mfcc_plan* plan) {
 int mfcc_execute_spectrogram(const mfcc_plan* plan, const float* d_pcm,
                              const int64_t* d_sample_offsets, const int64_t* d_frame_offsets,
                              int32_t n_utts, int64_t total_frames, float* d_spec_out,
-                             void* d_workspace, size_t workspace_bytes, void* stream) {
+                             void* d_workspace, size_t workspace_bytes, void* stream) try {
     int rc = check_batch(plan, d_pcm, d_sample_offsets, d_frame_offsets, n_utts, total_frames);
     if (rc != MFCC_OK) return rc;
     if (n_utts == 0 || total_frames == 0) return MFCC_OK;
@@ -1502,10 +1514,10 @@ int mfcc_execute_spectrogram(const mfcc_plan* plan, const float* d_pcm,
                       nullptr, d_spec_out, static_cast<char*>(d_workspace), L, static_cast<hipStream_t>(stream), prof.ev);
     if (rc != MFCC_OK) return rc;
     return finish_prof_slot(plan, prof, static_cast<hipStream_t>(stream));
-}
+} MFCC_CATCH_ALL
 
 int mfcc_cmvn_accumulate(const float* d_feats, int64_t n_rows, int32_t n_mfcc, double* d_stats,
-                         void* stream) {
+                         void* stream) try {
     if (n_rows < 0 || n_mfcc < 1 || n_mfcc > 256) return fail(MFCC_E_INVALID, "bad CMVN shape");
     if (n_rows == 0) return MFCC_OK;
     if (!d_feats || !d_stats) return fail(MFCC_E_INVALID, "NULL CMVN buffer");
@@ -1517,10 +1529,10 @@ int mfcc_cmvn_accumulate(const float* d_feats, int64_t n_rows, int32_t n_mfcc, d
                        static_cast<hipStream_t>(stream), d_feats, n_rows, n_mfcc, d_stats);
     HIP_TRY(hipGetLastError());
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
 int mfcc_cmvn_apply(float* d_feats, int64_t n_rows, int32_t n_mfcc, const double* d_stats, double eps,
-                    void* stream) {
+                    void* stream) try {
     if (n_rows < 0 || n_mfcc < 1) return fail(MFCC_E_INVALID, "bad CMVN shape");
     if (n_rows == 0) return MFCC_OK;
     if (!d_feats || !d_stats) return fail(MFCC_E_INVALID, "NULL CMVN buffer");
@@ -1530,10 +1542,10 @@ int mfcc_cmvn_apply(float* d_feats, int64_t n_rows, int32_t n_mfcc, const double
                        n_rows, n_mfcc, d_stats, eps);
     HIP_TRY(hipGetLastError());
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
 int mfcc_to_db(const float* d_in, int64_t n, int32_t amplitude, float ref, int32_t ref_is_max, float amin,
-               float top_db, float* d_out, void* d_workspace, void* stream) {
+               float top_db, float* d_out, void* d_workspace, void* stream) try {
     if (n < 0) return fail(MFCC_E_INVALID, "negative size");
     if (!(amin > 0.0f)) return fail(MFCC_E_INVALID, "amin must be strictly positive");
     if (n == 0) return MFCC_OK;
@@ -1549,9 +1561,9 @@ int mfcc_to_db(const float* d_in, int64_t n, int32_t amplitude, float ref, int32
     hipLaunchKernelGGL(k_to_db, dim3(blocks), dim3(256), 0, st, d_in, n, amplitude, r, ref_is_max, am, top_db, gmax, d_out);
     HIP_TRY(hipGetLastError());
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
-int mfcc_dct(const mfcc_plan* plan, const float* d_logmel, int64_t rows, float* d_out, void* stream) {
+int mfcc_dct(const mfcc_plan* plan, const float* d_logmel, int64_t rows, float* d_out, void* stream) try {
     if (!plan) return fail(MFCC_E_INVALID, "plan is NULL");
     if (rows < 0) return fail(MFCC_E_INVALID, "rows must be non-negative");
     if (rows == 0) return MFCC_OK;
@@ -1568,10 +1580,10 @@ int mfcc_dct(const mfcc_plan* plan, const float* d_logmel, int64_t rows, float* 
                        plan->r.c.n_mfcc, plan->n_rt);
     HIP_TRY(hipGetLastError());
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
 int mfcc_delta(const float* d_feats, const int64_t* d_frame_offsets, const int64_t* h_frame_offsets, int32_t n_utts,
-               int32_t n_coef, int32_t width, int32_t order, float* d_out, void* stream) {
+               int32_t n_coef, int32_t width, int32_t order, float* d_out, void* stream) try {
     if (n_utts < 0 || n_coef < 1) return fail(MFCC_E_INVALID, "bad delta shape");
     if (width < 3 || width % 2 == 0 || width > DELTA_MAX_WIDTH)
         return fail(MFCC_E_INVALID, "width must be an odd integer >= 3 (and at most 65)");
@@ -1630,7 +1642,7 @@ int mfcc_delta(const float* d_feats, const int64_t* d_frame_offsets, const int64
     hipLaunchKernelGGL(k_delta, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return MFCC_OK;
-}
+} MFCC_CATCH_ALL
 
 int mfcc_host_pcm16_from_float(const float* h_src, int64_t n, int16_t* h_dst) {
     if (n < 0 || (n > 0 && (!h_src || !h_dst))) return fail(MFCC_E_INVALID, "bad host buffers");
