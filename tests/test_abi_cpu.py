@@ -193,3 +193,27 @@ def test_header_is_plain_c_and_host_entry_points_work_from_c(tmp_path):
     assert arr.shape == (3, 13) and arr[0, 0] == 13.0
     assert attrs == dict(speaker_id=10, chapter_id=20, utterance_id=1, sample_rate=16000, transcript="SECOND")
     assert not (tmp_path / "mfcc.partial").exists()
+
+
+def test_host_entry_points_under_randomised_inputs(tmp_path):
+    """tests/csrc/host_stress.cpp against the in-tree library: tables, batch layouts, packing ranges
+    and the file writers over a few hundred random cases each, with buffers of exactly the documented
+    sizes and the arguments that must be refused.  (tools/host_sanitize.sh runs the same program
+    against builds whose host code carries AddressSanitizer + UBSan and ThreadSanitizer.)"""
+    import shutil
+    import subprocess
+
+    from speech_to_text_amd import _lib
+
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    root = Path(__file__).resolve().parent.parent
+    lib = _lib.library_path()
+    exe = tmp_path / "host_stress"
+    subprocess.run([gxx, "-std=c++17", "-O1", "-Wall", "-I", str(root / "include"), str(root / "tests" / "csrc" / "host_stress.cpp"),
+                    str(lib), "-Wl,--allow-shlib-undefined", f"-Wl,-rpath,{lib.parent}", "-pthread", "-o", str(exe)], check=True)
+    out = tmp_path / "files"
+    out.mkdir()
+    r = subprocess.run([str(exe), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "host_stress_ok" in r.stdout, r.stdout + r.stderr
