@@ -286,3 +286,30 @@ def test_oracle_agrees_with_an_independent_librosa_compatible_implementation(n_f
     m_other = scipy.fftpack.dct(spec, axis=-2, type=2, norm="ortho")[:13]
     m_ours = R.mfcc(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, n_mfcc=13, pad_mode=pad_mode)
     assert np.abs(m_other - m_ours).max() <= 1e-3
+
+
+@pytest.mark.parametrize("n_fft,hop,win,center,pad_mode", [
+    (2048, 512, None, True, "constant"),      # the reference's call, /root/reference/src/preprocess.py:134
+    (2048, 512, None, True, "reflect"),
+    (512, 160, 400, True, "constant"),        # a window shorter than the transform, centred in it
+    (400, 160, None, True, "reflect"),
+    (1024, 333, 1000, False, "constant"),     # no centring, a hop that divides nothing
+    (256, 64, 255, True, "reflect"),          # an odd window length: the extra zero goes to the right
+])
+def test_stft_agrees_with_torch_stft(n_fft, hop, win, center, pad_mode):
+    """A second independent witness for the framing conventions: ``torch.stft`` (its centring,
+    pad modes and the centring of a short window inside n_fft were written to match librosa's),
+    run in float64 with scipy's periodic Hann.  Frame count, every frame's position and the
+    transform agree with the oracle to complex64 rounding."""
+    import torch
+
+    y = speech_like(30011, seed=21, int16_grid=True)
+    wl = n_fft if win is None else win
+    window = torch.from_numpy(R.get_window("hann", wl, fftbins=True))
+    want = torch.stft(torch.from_numpy(y.astype(np.float64)), n_fft=n_fft, hop_length=hop, win_length=wl, window=window,
+                      center=center, pad_mode=pad_mode, normalized=False, onesided=True, return_complex=True).numpy()
+    got = R.stft(y, n_fft=n_fft, hop_length=hop, win_length=win, center=center, pad_mode=pad_mode)
+    assert got.dtype == np.complex64 and got.shape == want.shape
+    assert got.shape[-1] == R.n_frames(len(y), n_fft, hop, center)
+    scale = np.abs(want).max(axis=0, keepdims=True)            # per frame: the edge frames count as much as the rest
+    assert (np.abs(got - want) / scale).max() <= 2e-7
