@@ -1,5 +1,5 @@
 // Front end for n_fft = 16 A with A = 25 or any even A from 8 to 62 that is not a power of two
-// (built: n_fft = 128, 160, 192, 320, 384, 400, 480, 576, 640, 768, 800, 960 -- the 8 .. 60 ms
+// (n_fft = 400 and every multiple of 32 from 128 to 992 that is not a power of two: the 8 .. 60 ms
 // windows of 16 kHz speech front ends, or shorter ones at 32 / 48 kHz, taken as the transform
 // length, e.g. n_fft = 400, hop 160, 80 mels) on gfx950: one wavefront per four consecutive
 // frames, no barriers in the frame loop.

@@ -580,8 +580,9 @@ struct mfcc_plan {
     float* d_lifter = nullptr;
     float* d_dfrag = nullptr;
     // in-register FFT front ends other than 2048: 0 (none), 8 / 9 / 10 = log2(n_fft) for the
-    // power-of-two kernel (front_pow2.h), or 400 for the 400-point kernel (front_400.h)
+    // power-of-two kernel (front_pow2.h), or n_fft itself for the 16 A kernels (front_400.h)
     int small_fft = 0, p2_waves = 0, p2_quads = 0, p2_rounds = 0;
+    char small_name[16] = {0};                       // "fft<n_fft>" when small_fft names a 16 A length
     size_t p2_lds_bytes = 0;
     float2* d_p2_tw1 = nullptr;
     float4* d_p2_melw = nullptr;
@@ -721,15 +722,17 @@ Pow2Fn k16a_pick(bool pw2, bool pcm16) {
 }
 // small_fft: 8, 9, 10 for the power-of-two kernels; n_fft itself for the 16 A kernels (front_400.h).
 // Wavefronts per workgroup follow the region size and the registers the A-point transform needs:
-// 16 up to A = 30, 12 up to A = 40 (12 KB regions), 8 beyond; 8 is also the fallback of the
-// lengths that were built first when a large filterbank leaves less LDS.
-#define MFCC_16A_LENGTHS(X) X(8) X(10) X(12) X(20) X(24) X(25) X(30) X(36) X(40) X(48) X(50) X(60)
-constexpr int k16a_waves(int A) { return A <= 30 ? 16 : (A <= 40 ? 12 : 8); }
-constexpr bool k16a_has_fallback(int A) { return A == 20 || A == 25 || A == 30 || A == 40; }
+// 16 up to A = 25 and at 30, 12 up to A = 40 (12 KB regions), 8 beyond, 6 at A = 62 (18 KB regions).
+// A second, smaller count takes over when a large filterbank leaves less LDS: 8 for the lengths
+// that were built first, 4 for the longest three.
+#define MFCC_16A_LENGTHS(X) X(8) X(10) X(12) X(14) X(18) X(20) X(22) X(24) X(25) X(26) X(28) X(30) X(34) X(36) X(38) \
+    X(40) X(42) X(44) X(46) X(48) X(50) X(52) X(54) X(56) X(58) X(60) X(62)
+constexpr int k16a_waves(int A) { return (A <= 25 || A == 30) ? 16 : (A <= 40 ? 12 : (A <= 60 ? 8 : 6)); }
+constexpr int k16a_fallback_waves(int A) { return (A == 20 || A == 25 || A == 30 || A == 40) ? 8 : (A >= 58 ? 4 : 0); }
 template <int A>
 Pow2Fn k16a_kernel(int waves, bool pw2, bool pcm16) {
-    if constexpr (k16a_has_fallback(A)) {
-        if (waves != k16a_waves(A)) return k16a_pick<A, 8>(pw2, pcm16);
+    if constexpr (k16a_fallback_waves(A) != 0) {
+        if (waves != k16a_waves(A)) return k16a_pick<A, k16a_fallback_waves(A)>(pw2, pcm16);
     }
     return k16a_pick<A, k16a_waves(A)>(pw2, pcm16);
 }
@@ -841,9 +844,9 @@ bool build_16a_tables(mfcc_plan* p, const std::vector<float>& basis, std::vector
                         &p->p2_quads, &p->p2_rounds))
         return false;
     p->p2_waves = 0;
-    const char* force = std::getenv("MFCC_HIP_P2_WAVES");      // experiments: the length's own count or 8
-    for (int w : {k16a_waves(A), 8})
-        if ((w == k16a_waves(A) || k16a_has_fallback(A)) && (!force || std::atoi(force) == w) &&
+    const char* force = std::getenv("MFCC_HIP_P2_WAVES");      // experiments: the length's own count or its fallback
+    for (int w : {k16a_waves(A), k16a_fallback_waves(A)})
+        if (w != 0 && (!force || std::atoi(force) == w) &&
             G::lds_bytes(w, p->p2_quads, p->p2_rounds) <= (size_t)k2048::LDS_LIMIT) {
             p->p2_waves = w;
             break;
@@ -1060,6 +1063,7 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) try {
         if (r.c.n_fft == 16 * A && build_16a_tables<A>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 16 * A;
         MFCC_16A_LENGTHS(MFCC_16A_TABLES)
 #undef MFCC_16A_TABLES
+        if (p->small_fft) std::snprintf(p->small_name, sizeof p->small_name, "fft%d", p->small_fft);
         if (r.c.n_fft == 256 && build_pow2_tables<8>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 8;
         if (r.c.n_fft == 512 && build_pow2_tables<9>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 9;
         if (r.c.n_fft == 1024 && build_pow2_tables<10>(p, basis, p2_tw1, p2_melw, p2_pairs)) p->small_fft = 10;
@@ -1475,21 +1479,7 @@ int mfcc_workspace_status(const void* d_workspace, void* stream) try {
 const char* mfcc_plan_front_kernel(const mfcc_plan* plan) {
     if (!plan) return nullptr;
     if (plan->fast2048) return "fft2048";
-    switch (plan->small_fft) {
-        case 128: return "fft128";
-        case 160: return "fft160";
-        case 192: return "fft192";
-        case 320: return "fft320";
-        case 384: return "fft384";
-        case 400: return "fft400";
-        case 480: return "fft480";
-        case 576: return "fft576";
-        case 640: return "fft640";
-        case 768: return "fft768";
-        case 800: return "fft800";
-        case 960: return "fft960";
-        default: break;
-    }
+    if (plan->small_fft > 10) return plan->small_name;      // "fft<n_fft>" of a 16 A length
     if (plan->small_fft == 8) return "fft256";
     if (plan->small_fft == 9) return "fft512";
     if (plan->small_fft == 10) return "fft1024";

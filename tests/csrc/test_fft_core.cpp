@@ -69,18 +69,20 @@ int main() {
     double worst = 0.0;
     srand(7);
     worst = fmax(worst, check_rdft25());
-    worst = fmax(worst, check_rdft_even<20>());
-    worst = fmax(worst, check_rdft_even<30>());
-    worst = fmax(worst, check_rdft_even<40>());
-    worst = fmax(worst, check_rdft_even<50>());
-    worst = fmax(worst, check_rdft_even<60>());
-    worst = fmax(worst, check_rdft_even<8>());
-    worst = fmax(worst, check_rdft_even<10>());
-    worst = fmax(worst, check_rdft_even<12>());
-    worst = fmax(worst, check_rdft_even<24>());
-    worst = fmax(worst, check_rdft_even<36>());
-    worst = fmax(worst, check_rdft_even<48>());
-    worst = fmax(worst, check_rdft_even<62>());
+    // every even length the 16 A front end is built for
+    worst = fmax(worst, check_rdft_even<8>()); worst = fmax(worst, check_rdft_even<10>());
+    worst = fmax(worst, check_rdft_even<12>()); worst = fmax(worst, check_rdft_even<14>());
+    worst = fmax(worst, check_rdft_even<18>()); worst = fmax(worst, check_rdft_even<20>());
+    worst = fmax(worst, check_rdft_even<22>()); worst = fmax(worst, check_rdft_even<24>());
+    worst = fmax(worst, check_rdft_even<26>()); worst = fmax(worst, check_rdft_even<28>());
+    worst = fmax(worst, check_rdft_even<30>()); worst = fmax(worst, check_rdft_even<34>());
+    worst = fmax(worst, check_rdft_even<36>()); worst = fmax(worst, check_rdft_even<38>());
+    worst = fmax(worst, check_rdft_even<40>()); worst = fmax(worst, check_rdft_even<42>());
+    worst = fmax(worst, check_rdft_even<44>()); worst = fmax(worst, check_rdft_even<46>());
+    worst = fmax(worst, check_rdft_even<48>()); worst = fmax(worst, check_rdft_even<50>());
+    worst = fmax(worst, check_rdft_even<52>()); worst = fmax(worst, check_rdft_even<54>());
+    worst = fmax(worst, check_rdft_even<56>()); worst = fmax(worst, check_rdft_even<58>());
+    worst = fmax(worst, check_rdft_even<60>()); worst = fmax(worst, check_rdft_even<62>());
     // the series behind the trigonometric constants of lengths without a literal table: within
     // 5e-15 of libm everywhere, and float for float what the literal tables hold
     for (int A = 2; A <= 64; ++A)

@@ -574,3 +574,52 @@ def test_reflect_padding_of_tail_frames_follows_librosa_slices(S, n_fft, hop, ar
     np.testing.assert_allclose(S.mfcc(y=y, n_fft=n_fft, hop_length=hop, pad_mode="reflect", n_mfcc=13, sr=sr, n_mels=n_mels),
                                R.mfcc(y=y, n_fft=n_fft, hop_length=hop, pad_mode="reflect", n_mfcc=13, sr=sr, n_mels=n_mels),
                                rtol=0, atol=DB_TOL)
+
+
+# n_fft = 16 A for every even A from 8 to 62 that has no power-of-two kernel: every multiple of 32
+# from 128 to 992 except 256 and 512
+MULTIPLES_OF_32 = [n for n in range(128, 993, 32) if n not in (256, 512)]
+
+
+@pytest.mark.parametrize("n_fft", MULTIPLES_OF_32)
+def test_every_multiple_of_32_runs_in_registers(S, n_fft, monkeypatch):
+    """Each of these lengths has an in-register kernel of its own ('fft<n_fft>'), which matches the
+    oracle on a ragged batch (odd hop, edge frames, an utterance shorter than a frame, both pad
+    modes by turns, a window shorter than the transform every third length) to the parity
+    tolerance, the |X|^2 tap included, and the dense-DFT kernel on the same batch."""
+    import warnings
+
+    import torch
+
+    i = MULTIPLES_OF_32.index(n_fft)
+    kw = dict(n_fft=n_fft, hop_length=n_fft // 4 + 1, n_mels=40 if n_fft < 320 else 80, n_mfcc=13, sr=16000,
+              pad_mode="reflect" if i % 2 else "constant")
+    if i % 3 == 2:
+        kw["win_length"] = n_fft - 2 * (i + 1) - 1
+    cfg = S.make_config(**kw)
+    plan = S.MfccPlan(cfg)
+    assert plan.front_kernel == f"fft{n_fft}"
+    ys = [speech_like(n, seed=300 + i + j) for j, n in enumerate([20011, n_fft // 3, 4 * n_fft + 5, n_fft])]
+    so = np.zeros(len(ys) + 1, dtype=np.int64)
+    np.cumsum([len(y) for y in ys], out=so[1:])
+    pcm = torch.from_numpy(np.concatenate(ys)).cuda()
+    fo = plan.frame_offsets(so)
+    got = plan.execute(pcm, torch.from_numpy(so).cuda(), torch.from_numpy(fo).cuda(), int(fo[-1])).cpu().numpy()
+    plan.close()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for u, y in enumerate(ys):
+            want = R.mfcc(y=y, **kw).T
+            np.testing.assert_allclose(got[int(fo[u]):int(fo[u + 1])], want, rtol=0, atol=DB_TOL)
+        y = ys[0]
+        skw = {k: v for k, v in kw.items() if k in ("n_fft", "hop_length", "win_length", "pad_mode")}
+        want = np.abs(R.stft(y, **skw)) ** 2
+        spec = S.spectrogram(y=y, power=2.0, **skw)
+    assert spec.shape == want.shape
+    assert (np.abs(spec - want) <= 1e-4 * want + 2e-6 * want.max(axis=0, keepdims=True)).all()
+    monkeypatch.setenv("MFCC_HIP_DENSE_DFT", "1")
+    dense = S.MfccPlan(cfg)
+    assert dense.front_kernel == "dense_dft"
+    other = dense.execute(pcm, torch.from_numpy(so).cuda(), torch.from_numpy(fo).cuda(), int(fo[-1])).cpu().numpy()
+    dense.close()
+    assert np.abs(got - other).max() <= DB_TOL
