@@ -5,15 +5,27 @@ traffic of the dominant kernel from separate --pmc passes.
 HBM bytes follow the MI355X guide's counter notes: TCC_EA0_RDREQ counts fabric read requests of
 32, 64 or 128 bytes (the 128-byte ones are the wide coalesced reads that FETCH_SIZE tallies at
 half their size on gfx950), TCC_EA0_WRREQ counts 32- or 64-byte write requests."""
-import csv, glob, json, sys, collections, shutil
+import csv, glob, json, os, sys, collections, shutil
 from pathlib import Path
+
+
+def newest_per_directory(paths):
+    """gpurun merges every run's files into the same local directory (rocprofv3 names them by
+    process id): of each directory only the most recent file belongs to the run being summarised."""
+    best = {}
+    for q in paths:
+        d = os.path.dirname(q)
+        if d not in best or os.path.getmtime(q) > os.path.getmtime(best[d]):
+            best[d] = q
+    return sorted(best.values())
+
 
 src = Path(sys.argv[1]); tag = sys.argv[2]
 command = sys.argv[3] if len(sys.argv) > 3 else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 out = Path(__file__).resolve().parent.parent / "profiles"
 out.mkdir(exist_ok=True)
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
-for path in glob.glob(str(src / "**/*counter_collection.csv"), recursive=True):
+for path in newest_per_directory(glob.glob(str(src / "**/*counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(path)):
         vals[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {}
@@ -28,7 +40,7 @@ for k, cs in vals.items():
     summary[k] = {"counters_mean_per_launch": m, "hbm_read_bytes": read_b, "hbm_write_bytes": write_b,
                   "hbm_bytes": read_b + write_b,
                   "fetch_size_x2_plus_write_size_bytes": (2 * m.get("FETCH_SIZE", 0) + m.get("WRITE_SIZE", 0)) * 1024}
-stats = sorted(glob.glob(str(src / "trace/**/*kernel_stats.csv"), recursive=True))
+stats = newest_per_directory(glob.glob(str(src / "trace/**/*kernel_stats.csv"), recursive=True))
 rows = []
 if stats:
     shutil.copy(stats[0], out / f"{tag}_bench_kernel_stats.csv")
@@ -42,6 +54,9 @@ if log.exists():
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from bench import csrc_sha256  # noqa: E402  (bench.py quotes this profile only for the same kernel sources)
 
+ran = ((bench_line or {}).get("roofline") or {}).get("csrc_sha256")
+if ran is not None and ran != csrc_sha256():
+    sys.exit(f"the profiled run used a library built from other kernel sources ({ran[:12]}) than the tree holds ({csrc_sha256()[:12]})")
 json.dump({"command": f"rocprofv3 ... -- {command} (one run per counter set)",
            "csrc_sha256": csrc_sha256(),
            "kernels": summary, "kernel_stats": rows, "bench_line_under_profiler": bench_line},
