@@ -7,7 +7,8 @@
 //   rdft32 : 32-point DFT of a REAL sequence (bins 0..16) from one cfft16 of the packed
 //            sequence z[m] = r[2m] + i r[2m+1] plus the conjugate-symmetric split.
 //   rdft_cols<R> : the same for 2R = 4, 8, 16 points;  rdft25 : 25-point real DFT (5 x 5);
-//   rdft_even<A> : real DFTs of any even length A (8 .. 62 are used), folded direct sums.
+//   rdft_even<A> : real DFTs of any even length A (8 .. 62 are used), folded direct sums;
+//   rdft_odd<A>  : the same for odd A (9 .. 61 are used).
 //
 // Forward transform convention, as numpy.fft: X[k] = sum_n x[n] exp(-2 pi i n k / N).
 #pragma once
@@ -534,6 +535,33 @@ FC_HD void rdft_even(const float (&x)[A], float (&yr)[A / 2 + 1], float (&yi)[A 
             const float cs = TrigTable<A>::cosv((a * c) % A), sn = TrigTable<A>::sinv((a * c) % A);
             re = fmaf((c % 2 == 0) ? pe[a] : po[a], cs, re);
             im = fmaf((c % 2 == 0) ? qe[a] : qo[a], sn, im);
+        }
+        yr[c] = re;
+        yi[c] = -im;
+    }
+}
+
+// Real A-point DFT for odd A, bins 0 .. (A - 1) / 2, by the direct sum folded once: with
+// H = (A - 1) / 2, p[a] = x[a] + x[A-a] and q[a] = x[a] - x[A-a] (a = 1 .. H),
+//     Re Y[c] = x[0] + sum_a p[a] cos(2 pi a c / A),   Im Y[c] = -sum_a q[a] sin(2 pi a c / A).
+// All trigonometric factors are literals: 2 H fused multiply-adds per bin.
+template <int A>
+FC_HD void rdft_odd(const float (&x)[A], float (&yr)[A / 2 + 1], float (&yi)[A / 2 + 1]) {
+    static_assert(A % 2 == 1 && A >= 3, "rdft_odd: A must be odd");
+    constexpr int H = A / 2;
+    float p[H + 1], q[H + 1];
+#pragma unroll
+    for (int a = 1; a <= H; ++a) {
+        p[a] = x[a] + x[A - a];
+        q[a] = x[a] - x[A - a];
+    }
+#pragma unroll
+    for (int c = 0; c <= H; ++c) {
+        float re = x[0], im = 0.0f;
+#pragma unroll
+        for (int a = 1; a <= H; ++a) {
+            re = fmaf(p[a], TrigTable<A>::cosv((a * c) % A), re);
+            im = fmaf(q[a], TrigTable<A>::sinv((a * c) % A), im);
         }
         yr[c] = re;
         yi[c] = -im;

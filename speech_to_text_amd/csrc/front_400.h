@@ -1,5 +1,5 @@
-// Front end for n_fft = 16 A with A = 25 or any even A from 8 to 62 that is not a power of two
-// (n_fft = 400 and every multiple of 32 from 128 to 992 that is not a power of two: the 8 .. 60 ms
+// Front end for n_fft = 16 A with any A from 8 to 63 that is not a power of two (every multiple
+// of 16 from 128 to 1008 but 256 and 512: the 8 .. 60 ms
 // windows of 16 kHz speech front ends, or shorter ones at 32 / 48 kHz, taken as the transform
 // length, e.g. n_fft = 400, hop 160, 80 mels) on gfx950: one wavefront per four consecutive
 // frames, no barriers in the frame loop.
@@ -13,7 +13,7 @@
 //     W_N^(n k) = W_A^(a c) W_N^(b c) W_16^(b d)
 //  step 1  lane (t = lane>>4, b = lane&15) holds the A samples a = 0..A-1 of frame t and computes
 //          the real A-point DFT over a for c = 0..A/2 in registers (fc::rdft25: 5 x 5;
-//          fc::rdft_even<20 / 30>: folded direct sums)
+//          fc::rdft_even / fc::rdft_odd: folded direct sums)
 //  twiddle Z[b][c] = Y[b][c] W_N^(b c)
 //  exchange through LDS: column (t, c) = 16 complex, columns 36 floats apart (conflict-free
 //          16-byte reads)
@@ -33,12 +33,39 @@
 #define MFCC_16A_WIN_LDS (~0ULL << 30)
 #endif
 
+// The lengths that are built, as A = n_fft / 16.  Wavefronts per workgroup follow the region size
+// and the registers the A-point transform needs: 16 up to A = 25 and at 30, 12 up to A = 40 (12 KB
+// regions), 8 beyond, 6 from A = 61 on (18 KB regions).  A second, smaller count takes over when a large
+// filterbank leaves less LDS: 8 for the lengths that were built first, 4 for the longest three.
+#define MFCC_16A_LENGTHS(X) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) \
+    X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) \
+    X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63)
+constexpr int k16a_waves(int A) { return (A <= 25 || A == 30) ? 16 : (A <= 40 ? 12 : (A <= 60 ? 8 : 6)); }
+constexpr int k16a_fallback_waves(int A) { return (A == 20 || A == 25 || A == 30 || A == 40) ? 8 : (A >= 57 ? 4 : 0); }
+// The kernels are instantiated in front_400_inst.hip, which is compiled MFCC_16A_PARTS times (the
+// lengths dealt round-robin over the parts) so that the build runs in parallel; part k exports
+// k16a_lookup_part<k>(n_fft, waves, power == 2, 16-bit PCM) -> kernel, or nullptr for a length or
+// wavefront count that is not its own.
+#define MFCC_16A_PARTS 6
+constexpr int k16a_part(int A) {
+    int i = 0;
+#define MFCC_16A_INDEX(B) if (B == A) return i % MFCC_16A_PARTS; ++i;
+    MFCC_16A_LENGTHS(MFCC_16A_INDEX)
+#undef MFCC_16A_INDEX
+    return -1;
+}
+typedef void (*Pow2Fn)(const Pow2Args);
+#define MFCC_16A_FOR_EACH_PART(X) X(0) X(1) X(2) X(3) X(4) X(5)
+#define MFCC_16A_DECLARE_PART(K) Pow2Fn k16a_lookup_part##K(int n_fft, int waves, bool pw2, bool pcm16);
+MFCC_16A_FOR_EACH_PART(MFCC_16A_DECLARE_PART)
+#undef MFCC_16A_DECLARE_PART
+
 namespace k16a {
 constexpr int T = 4;                    // frames per wavefront pass
 constexpr int COL = 36;                 // floats per exchange column: 16 complex + 4 floats of padding
 template <int A>
 struct Geo {
-    static_assert(A == 25 || (A % 2 == 0 && A >= 8 && A <= 62), "supported: n_fft = 400 and 16 x an even number in 8 .. 62");
+    static_assert(A >= 8 && A <= 63, "supported: n_fft = 16 A for A in 8 .. 63");
     static constexpr int N = 16 * A, NB = N / 2 + 1, NA = A, NC = A / 2 + 1;   // NC columns per frame
     static constexpr int ROUNDS = (T * NC + 63) / 64;                          // step-2 columns per lane
     static_assert(ROUNDS <= 2, "at most two columns per lane");
@@ -66,7 +93,8 @@ static_assert(Geo<25>::P_STRIDE == 272 && Geo<25>::REGION == k2048::XCH_FLOATS, 
 template <int A>
 __device__ __forceinline__ void rdft_a(const float (&x)[A], float (&yr)[A / 2 + 1], float (&yi)[A / 2 + 1]) {
     if constexpr (A == 25) fc::rdft25(x, yr, yi);
-    else fc::rdft_even<A>(x, yr, yi);
+    else if constexpr (A % 2 == 0) fc::rdft_even<A>(x, yr, yi);
+    else fc::rdft_odd<A>(x, yr, yi);
 }
 }  // namespace k16a
 

@@ -709,38 +709,22 @@ int select_variant(mfcc_plan* p) {
     return MFCC_OK;
 }
 
-typedef void (*Pow2Fn)(const Pow2Args);
 template <int L, int W>
 Pow2Fn pow2_pick(bool pw2, bool pcm16) {
     if (pw2) return pcm16 ? k_melspec_pow2<L, W, 0, true> : k_melspec_pow2<L, W, 0, false>;
     return pcm16 ? k_melspec_pow2<L, W, 1, true> : k_melspec_pow2<L, W, 1, false>;
 }
-template <int A, int W>
-Pow2Fn k16a_pick(bool pw2, bool pcm16) {
-    if (pw2) return pcm16 ? k_melspec_16a<A, W, 0, true> : k_melspec_16a<A, W, 0, false>;
-    return pcm16 ? k_melspec_16a<A, W, 1, true> : k_melspec_16a<A, W, 1, false>;
-}
-// small_fft: 8, 9, 10 for the power-of-two kernels; n_fft itself for the 16 A kernels (front_400.h).
-// Wavefronts per workgroup follow the region size and the registers the A-point transform needs:
-// 16 up to A = 25 and at 30, 12 up to A = 40 (12 KB regions), 8 beyond, 6 at A = 62 (18 KB regions).
-// A second, smaller count takes over when a large filterbank leaves less LDS: 8 for the lengths
-// that were built first, 4 for the longest three.
-#define MFCC_16A_LENGTHS(X) X(8) X(10) X(12) X(14) X(18) X(20) X(22) X(24) X(25) X(26) X(28) X(30) X(34) X(36) X(38) \
-    X(40) X(42) X(44) X(46) X(48) X(50) X(52) X(54) X(56) X(58) X(60) X(62)
-constexpr int k16a_waves(int A) { return (A <= 25 || A == 30) ? 16 : (A <= 40 ? 12 : (A <= 60 ? 8 : 6)); }
-constexpr int k16a_fallback_waves(int A) { return (A == 20 || A == 25 || A == 30 || A == 40) ? 8 : (A >= 58 ? 4 : 0); }
-template <int A>
-Pow2Fn k16a_kernel(int waves, bool pw2, bool pcm16) {
-    if constexpr (k16a_fallback_waves(A) != 0) {
-        if (waves != k16a_waves(A)) return k16a_pick<A, k16a_fallback_waves(A)>(pw2, pcm16);
-    }
-    return k16a_pick<A, k16a_waves(A)>(pw2, pcm16);
+// small_fft: 8, 9, 10 for the power-of-two kernels; n_fft itself for the 16 A kernels, which live
+// in front_400_inst.hip (lengths and wavefront counts: front_400.h).
+Pow2Fn k16a_kernel(int n_fft, int waves, bool pw2, bool pcm16) {
+#define MFCC_16A_TRY_PART(K) if (Pow2Fn fn = k16a_lookup_part##K(n_fft, waves, pw2, pcm16)) return fn;
+    MFCC_16A_FOR_EACH_PART(MFCC_16A_TRY_PART)
+#undef MFCC_16A_TRY_PART
+    return nullptr;
 }
 Pow2Fn pow2_kernel(const mfcc_plan* p, bool pcm16) {
     const bool pw2 = p->r.c.power == 2.0f;
-#define MFCC_16A_CASE(A) if (p->small_fft == 16 * A) return k16a_kernel<A>(p->p2_waves, pw2, pcm16);
-    MFCC_16A_LENGTHS(MFCC_16A_CASE)
-#undef MFCC_16A_CASE
+    if (p->small_fft > 10) return k16a_kernel(p->small_fft, p->p2_waves, pw2, pcm16);
     if (p->small_fft == 8) return p->p2_waves == 16 ? pow2_pick<8, 16>(pw2, pcm16) : pow2_pick<8, 8>(pw2, pcm16);
     if (p->small_fft == 9) return p->p2_waves == 16 ? pow2_pick<9, 16>(pw2, pcm16) : pow2_pick<9, 8>(pw2, pcm16);
     return p->p2_waves == 16 ? pow2_pick<10, 16>(pw2, pcm16) : pow2_pick<10, 8>(pw2, pcm16);

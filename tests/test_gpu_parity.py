@@ -576,13 +576,13 @@ def test_reflect_padding_of_tail_frames_follows_librosa_slices(S, n_fft, hop, ar
                                rtol=0, atol=DB_TOL)
 
 
-# n_fft = 16 A for every even A from 8 to 62 that has no power-of-two kernel: every multiple of 32
-# from 128 to 992 except 256 and 512
-MULTIPLES_OF_32 = [n for n in range(128, 993, 32) if n not in (256, 512)]
+# n_fft = 16 A for every A from 8 to 63 that has no power-of-two kernel: every multiple of 16 from
+# 128 to 1008 except 256 and 512
+MULTIPLES_OF_16 = [n for n in range(128, 1009, 16) if n not in (256, 512)]
 
 
-@pytest.mark.parametrize("n_fft", MULTIPLES_OF_32)
-def test_every_multiple_of_32_runs_in_registers(S, n_fft, monkeypatch):
+@pytest.mark.parametrize("n_fft", MULTIPLES_OF_16)
+def test_every_multiple_of_16_runs_in_registers(S, n_fft, monkeypatch):
     """Each of these lengths has an in-register kernel of its own ('fft<n_fft>'), which matches the
     oracle on a ragged batch (odd hop, edge frames, an utterance shorter than a frame, both pad
     modes by turns, a window shorter than the transform every third length) to the parity
@@ -591,11 +591,11 @@ def test_every_multiple_of_32_runs_in_registers(S, n_fft, monkeypatch):
 
     import torch
 
-    i = MULTIPLES_OF_32.index(n_fft)
+    i = MULTIPLES_OF_16.index(n_fft)
     kw = dict(n_fft=n_fft, hop_length=n_fft // 4 + 1, n_mels=40 if n_fft < 320 else 80, n_mfcc=13, sr=16000,
               pad_mode="reflect" if i % 2 else "constant")
     if i % 3 == 2:
-        kw["win_length"] = n_fft - 2 * (i + 1) - 1
+        kw["win_length"] = n_fft - (i + 1) - 1
     cfg = S.make_config(**kw)
     plan = S.MfccPlan(cfg)
     assert plan.front_kernel == f"fft{n_fft}"

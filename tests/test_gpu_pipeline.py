@@ -183,7 +183,9 @@ def test_int16_pcm_ingest_is_bit_identical(gpu, kw):
     (dict(n_fft=224, hop_length=112, n_mels=40, sr=16000), "fft224"),
     (dict(n_fft=448, hop_length=160, n_mels=80, sr=16000), "fft448"),
     (dict(n_fft=992, hop_length=480, n_mels=80, sr=48000), "fft992"),
-    (dict(n_fft=240, hop_length=80, n_mels=40, sr=8000), "dense_dft"),      # 16 x an odd number
+    (dict(n_fft=240, hop_length=80, n_mels=40, sr=8000), "fft240"),         # 16 x an odd number
+    (dict(n_fft=976, hop_length=480, n_mels=128, sr=44100), "fft976"),
+    (dict(n_fft=200, hop_length=80, n_mels=40, sr=8000), "dense_dft"),      # not a multiple of 16
     (dict(n_fft=4096, hop_length=1024), None),
     (dict(n_fft=2047, hop_length=512), None),
 ])

@@ -4,7 +4,6 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); N=$1; shift
 mkdir -p $R/build/ab
-cd $R/speech_to_text_amd/csrc
-/opt/rocm/bin/hipcc -fno-slp-vectorize -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -Wall -Wno-unused-function "$@" \
-    -x hip mfcc_hip.hip -x hip host_tables.cpp -x hip hdf5_file.cpp -o $R/build/ab/$N.so
+make -j8 -C $R/speech_to_text_amd/csrc OUT=$R/build/ab/$N.so OBJDIR=$R/build/ab/obj_$N EXTRA="$*" > /dev/null
+rm -rf $R/build/ab/obj_$N
 echo built build/ab/$N.so

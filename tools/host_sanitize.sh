@@ -1,7 +1,7 @@
 #!/bin/bash
 # Host code of the library under sanitizers (the GPU code is built as usual and not run):
 #   1. AddressSanitizer + UBSan   2. ThreadSanitizer
-# each a separate build of the whole library under build/, with tests/csrc/host_stress.cpp linked
+# each a separate build of the whole library under build/ (csrc/Makefile with HOSTFLAGS), with tests/csrc/host_stress.cpp linked
 # against it.  CPU only; about four minutes.  usage: tools/host_sanitize.sh [log file]
 set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
@@ -9,15 +9,11 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 CLANGXX="${CLANGXX:-/opt/rocm/lib/llvm/bin/clang++}"
 LOG="${1:-/dev/stdout}"
 case "$LOG" in /*) ;; *) LOG="$PWD/$LOG" ;; esac
-cd "$ROOT/speech_to_text_amd/csrc"
 run() {   # name, host flags...
     local name="$1"; shift
     local out="$ROOT/build/$name"
     mkdir -p "$out"
-    local xa=()
-    for f in "$@"; do xa+=(-Xarch_host "$f"); done
-    "$HIPCC" -fno-slp-vectorize -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 "${xa[@]}" -Wall -Wno-unused-function \
-        -x hip mfcc_hip.hip -x hip host_tables.cpp -x hip hdf5_file.cpp -o "$out/libmfcc_hip.so"
+    make -j8 -C "$ROOT/speech_to_text_amd/csrc" OUT="$out/libmfcc_hip.so" OBJDIR="$out/obj" HOSTFLAGS="$*" > /dev/null
     "$CLANGXX" -O1 -g -std=c++17 "$@" -I"$ROOT/include" "$ROOT/tests/csrc/host_stress.cpp" -o "$out/host_stress" \
         -L"$out" -lmfcc_hip -Wl,-rpath,"$out" -pthread
     local dir

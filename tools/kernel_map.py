@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Which front-end kernel serves which (n_fft, n_mels): builds a plan for every multiple of 32 from
-128 to 1024 plus 400 and 2048, at several filterbank sizes and sample rates, and prints the kernel
+"""Which front-end kernel serves which (n_fft, n_mels): builds a plan for every multiple of 16 from
+128 to 1024 plus 2048, at several filterbank sizes and sample rates, and prints the kernel
 names -- a 'dense_dft' in an in-register length's row means the filterbank did not fit its LDS.
     python tools/kernel_map.py [out.json]"""
 import json
@@ -12,7 +12,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import speech_to_text_amd as S  # noqa: E402
 
 warnings.simplefilter("ignore")
-lengths = sorted(set(range(128, 1025, 32)) | {400, 2048})
+lengths = sorted(set(range(128, 1025, 16)) | {2048})
 mels = (13, 23, 40, 64, 80, 128, 160, 256)
 rates = (8000, 16000, 22050, 48000)
 table, misses = {}, []
