@@ -94,7 +94,7 @@ class MfccPlan:
 
     @property
     def front_kernel(self) -> str:
-        """Which front-end kernel the plan runs: 'fft<n_fft>' for the in-register FFT kernels (n_fft 400, every multiple of 32 from 128 to 1024, and 2048) or 'dense_dft'."""
+        """Which front-end kernel the plan runs: 'fft<n_fft>' for the in-register FFT kernels (every multiple of 16 from 128 to 1024, and 2048) or 'dense_dft'."""
         return _lib.lib().mfcc_plan_front_kernel(self._handle).decode("ascii")
 
     # ------------------------------------------------------------------------------------
