@@ -9,7 +9,7 @@ TAG=${1:?usage: tools/profile_all.sh <tag>}; O=gpurun_out/$TAG; mkdir -p $O
 timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err
 cut -c1-300 $O/bench.json
 timeout -k 10 500 bash tools/pmc_traffic.sh ${TAG}_traffic > $O/traffic.txt 2>&1
-timeout -k 10 500 bash tools/sq_counters.sh ${TAG} 2 ref > $O/sq_ref.txt 2>&1
+timeout -k 10 800 bash tools/sq_counters.sh ${TAG} 10 ref > $O/sq_ref.txt 2>&1      # the bench's own 10-hour batch
 timeout -k 10 500 bash tools/sq_counters.sh ${TAG}_asr512 2 asr512 > $O/sq_asr512.txt 2>&1
 timeout -k 10 500 bash tools/sq_counters.sh ${TAG}_asr400 2 asr400 > $O/sq_asr400.txt 2>&1
 timeout -k 10 500 bash tools/sq_counters.sh ${TAG}_fft600 0.5 fft600 > $O/sq_fft600.txt 2>&1
