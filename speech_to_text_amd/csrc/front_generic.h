@@ -2,17 +2,23 @@
 //
 //   pad / frame / window -> DFT as an fp32 MFMA GEMM -> |X|^power -> sparse mel filterbank
 //
-// Used for every n_fft other than 2048 (e.g. the 400-point and 512-point ASR front ends), where
-// the DFT matrix is a genuine dense contraction: [16 frames x n_fft] . [n_fft x 2 n_bins] with
-// v_mfma_f32_16x16x4_f32.  Same role as front_2048.h: the stft + abs**power + mel einsum part of
-// librosa.feature.mfcc (/root/reference/src/preprocess.py:134) for non-default n_fft.
+// Used for every n_fft without an in-register FFT kernel (e.g. 600, 200, 1104), where the DFT is run
+// as a genuine dense contraction on v_mfma_f32_16x16x4_f32.  Same role as front_2048.h: the stft +
+// abs**power + mel einsum part of librosa.feature.mfcc (/root/reference/src/preprocess.py:134) for
+// such n_fft.  The real input is folded first: with p[m] = x[m] + x[N-m] and q[m] = x[m] - x[N-m]
+// (0 < m < N/2; p[0] = x[0], p[N/2] = x[N/2], q[0] = q[N/2] = 0),
+//     Re X[k] = sum_m p[m] cos(2 pi m k / N),    Im X[k] = -sum_m q[m] sin(2 pi m k / N),
+// i.e. two contractions [16 frames x (N/2 + 1)] . [(N/2 + 1) x n_bins], half the multiply-adds of
+// the unfolded [16 x N] . [N x 2 n_bins].
 //
 // One workgroup (4 wavefronts) per 16-frame tile:
-//   stage   each wavefront windows 4 frames into LDS, laid out so that the four A operands of
-//           four consecutive MFMA steps are one 16-byte read: sample n of frame f sits at float
-//           ((n & 3) * 16 + f) * lda + (n >> 2), lda = 4 * (odd number of quads) (conflict-free)
-//   DFT     wavefront w takes column tiles w, w+4, ...; columns interleave (cos, -sin) so a bin's
-//           real and imaginary parts sit in neighbouring lanes; power by one DPP swap
+//   stage   each wavefront windows and folds 4 frames into LDS, p and q apart, laid out so that
+//           the four A operands of four consecutive MFMA steps are one 16-byte read: element m of
+//           frame f sits at float ((m & 3) * 16 + f) * lda + (m >> 2), lda = 4 * (odd number of
+//           quads) (conflict-free)
+//   DFT     wavefront w takes the 16-bin column tiles w, w+4, ...: one accumulator chain for the
+//           real parts (p . cos), one for the imaginary parts (q . -sin), so a lane ends up with
+//           both parts of its (frame, bin) and squares them in place
 //   mel     wavefront w runs the lane-per-filter contraction on frames 4w .. 4w+3 from LDS P
 #pragma once
 #include <hip/hip_runtime.h>
@@ -26,7 +32,7 @@ struct GenArgs {
     const Tile* tiles;
     const WsHeader* hdr;
     const float* window;       // n_fft
-    const float* dfrag;        // [col tile][k step / 4][lane][4] DFT matrix in MFMA B-fragment order
+    const float* dfrag;        // [col tile][k step / 4][cos, -sin][lane][4] DFT matrices in MFMA B-fragment order
     const float4* melw;
     const int32_t* mel_start;
     const int32_t* mel_filt;
@@ -38,9 +44,9 @@ struct GenArgs {
     int32_t n_mels;
     int32_t n_fft;
     int32_t n_bins;
-    int32_t kpad;              // n_fft rounded up to a multiple of 16
-    int32_t n_coltiles;        // ceil(2 n_bins / 16)
-    int32_t lda;               // floats per (n & 3, frame) row of staged samples
+    int32_t kpad;              // n_fft / 2 + 1 (the folded length) rounded up to a multiple of 16
+    int32_t n_coltiles;        // ceil(n_bins / 16)
+    int32_t lda;               // floats per (m & 3, frame) row of folded samples
     int32_t ldp;               // floats per power-spectrum row (multiple of 4, + slack for mel over-read)
     int32_t hop;
     int32_t pad;
@@ -59,8 +65,8 @@ __global__ __launch_bounds__(256 * NT) void k_melspec_generic(const GenArgs a) {
     using namespace k2048;
     constexpr int THREADS = 256 * NT, WAVES = 4 * NT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* A = lds;                            // NT x 64 x lda
-    float* P = lds + NT * 64 * a.lda;          // NT x 16 x ldp
+    float* A = lds;                            // NT x {p, q} x 64 x lda
+    float* P = lds + NT * 128 * a.lda;         // NT x 16 x ldp
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tl = wave >> 2, wq = wave & 3;   // this wavefront stages / finishes frames 4 wq .. 4 wq + 3 of tile tl
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(256 * NT) void k_melspec_generic(const GenArgs a) {
 
     float runmax = 0.0f;
     int cur_grp = -1;
-    float* At = A + tl * 64 * a.lda;
+    float* At = A + tl * 128 * a.lda;           // p rows; the q rows follow 64 lda further on
     float* Pt = P + tl * 16 * a.ldp;
 
     for (int sup = blockIdx.x * per_wg; sup < super_end; ++sup) {
@@ -101,24 +107,38 @@ __global__ __launch_bounds__(256 * NT) void k_melspec_generic(const GenArgs a) {
         }
         __syncthreads();   // the previous pass's mel stage is done with P, its DFT with A
 
-        // ---- stage: pad + frame + window ------------------------------------------------------
+        // ---- stage: pad + frame + window + fold -------------------------------------------------
         const bool pcm16 = a.pcm16 != 0;
+        const int half = a.n_fft >> 1;
         for (int fi = 0; fi < 4; ++fi) {
             const int f = 4 * wq + fi;
             const int start = (ti.f0 + f) * a.hop - a.pad;
             const int lo = (a.reflect && a.pad) ? reflect_slice_start(start, ti.T, a.hop, a.n_fft) : 0;
-            for (int n = lane; n < a.kpad; n += 64) {
+            auto sample = [&](int n) -> float {          // windowed sample n of the frame (0 <= n < n_fft)
+                const int idx = start + n;
                 float v = 0.0f;
-                if (f < nvalid && n < a.n_fft) {
-                    const int idx = start + n;
-                    if (a.reflect) {
-                        if (ti.T > 0) v = load_sample(a.pcm, ti.soff + reflect_index(idx, ti.T, lo), pcm16);
-                    } else if (idx >= 0 && idx < ti.T) {
-                        v = load_sample(a.pcm, ti.soff + idx, pcm16);
-                    }
-                    v *= a.window[n];
+                if (a.reflect) {
+                    if (ti.T > 0) v = load_sample(a.pcm, ti.soff + reflect_index(idx, ti.T, lo), pcm16);
+                } else if (idx >= 0 && idx < ti.T) {
+                    v = load_sample(a.pcm, ti.soff + idx, pcm16);
                 }
-                At[((n & 3) * 16 + f) * a.lda + (n >> 2)] = v;
+                return v * a.window[n];
+            };
+            for (int m = lane; m < a.kpad; m += 64) {
+                float pv = 0.0f, qv = 0.0f;
+                if (f < nvalid && m <= half) {
+                    const float v = sample(m);
+                    if (m > 0 && m < half) {
+                        const float u = sample(a.n_fft - m);
+                        pv = v + u;
+                        qv = v - u;
+                    } else {
+                        pv = v;
+                    }
+                }
+                const int at = ((m & 3) * 16 + f) * a.lda + (m >> 2);
+                At[at] = pv;
+                At[64 * a.lda + at] = qv;
             }
         }
         __syncthreads();
@@ -126,59 +146,74 @@ __global__ __launch_bounds__(256 * NT) void k_melspec_generic(const GenArgs a) {
         // ---- DFT on the matrix cores, power, -> P ------------------------------------------------
         // lane supplies A[frame = lane & 15][k = 4 s + (lane >> 4)]: four steps per 16-byte read
         const float4* arow = reinterpret_cast<const float4*>(A + ((lane >> 4) * 16 + (lane & 15)) * a.lda);
-        const int tile_q = 16 * a.lda;        // float4 units between the tiles' staged samples
+        const int tile_q = 32 * a.lda;        // float4 units between the tiles' folded samples
+        const int q_off = 16 * a.lda;         // ... and from a tile's p rows to its q rows
         const int ks4 = a.kpad >> 4;
         for (int ct = wave; ct < a.n_coltiles; ct += WAVES) {
-            const float4* frag = reinterpret_cast<const float4*>(a.dfrag) + (size_t)ct * ks4 * 64 + lane;
-            gen_f32x4 acc0[NT], acc1[NT];
+            const float4* frag = reinterpret_cast<const float4*>(a.dfrag) + (size_t)ct * ks4 * 128 + lane;
+            gen_f32x4 acc_re[NT], acc_im[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) { acc0[t] = (gen_f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc1[t] = acc0[t]; }
-            int s = 0;
-            for (; s + 2 <= ks4; s += 2) {
-                float4 av[2][NT], bv[2];
+            for (int t = 0; t < NT; ++t) { acc_re[t] = (gen_f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc_im[t] = acc_re[t]; }
+            // The matrix fragments come from the L2 / memory-side cache, hundreds of cycles away, and a
+            // workgroup has one or two wavefronts per SIMD: they are requested a group of G steps
+            // (G x 8 NT products) ahead of their use, in registers.
+            constexpr int G = NT <= 2 ? 4 : 1;      // (short transforms, where NT is 3 or 4, have few steps: one ahead is enough)
+            float4 bc[G], bs[G];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    bv[j] = frag[(size_t)(s + j) * 64];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) av[j][t] = arow[t * tile_q + s + j];
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t].x, bv[j].x, acc0[t], 0, 0, 0);
-                        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t].y, bv[j].y, acc1[t], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t].z, bv[j].z, acc0[t], 0, 0, 0);
-                        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t].w, bv[j].w, acc1[t], 0, 0, 0);
-                    }
-                }
+            for (int j = 0; j < G; ++j) {
+                const int sj = min(j, ks4 - 1);
+                bc[j] = frag[(size_t)sj * 128];
+                bs[j] = frag[(size_t)sj * 128 + 64];
             }
-            for (; s < ks4; ++s) {
-                const float4 bv = frag[(size_t)s * 64];
+            for (int s0 = 0; s0 < ks4; s0 += G) {
+                float4 bc_next[G], bs_next[G];
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int sj = min(s0 + G + j, ks4 - 1);
+                    bc_next[j] = frag[(size_t)sj * 128];
+                    bs_next[j] = frag[(size_t)sj * 128 + 64];
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    if (s0 + j < ks4) {
+                        float4 ap[NT], aq[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) { ap[t] = arow[t * tile_q + s0 + j]; aq[t] = arow[t * tile_q + q_off + s0 + j]; }
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            acc_re[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[t].x, bc[j].x, acc_re[t], 0, 0, 0);
+                            acc_im[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[t].x, bs[j].x, acc_im[t], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            acc_re[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[t].y, bc[j].y, acc_re[t], 0, 0, 0);
+                            acc_im[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[t].y, bs[j].y, acc_im[t], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            acc_re[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[t].z, bc[j].z, acc_re[t], 0, 0, 0);
+                            acc_im[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[t].z, bs[j].z, acc_im[t], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            acc_re[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[t].w, bc[j].w, acc_re[t], 0, 0, 0);
+                            acc_im[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[t].w, bs[j].w, acc_im[t], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) { bc[j] = bc_next[j]; bs[j] = bs_next[j]; }
+            }
+            // acc[i]: frame 4 (lane >> 4) + i, bin 16 ct + (lane & 15)
+            const int bin = 16 * ct + (lane & 15);
+            if (bin < a.n_bins) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const float4 av = arow[t * tile_q + s];
-                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0[t], 0, 0, 0);
-                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1[t], 0, 0, 0);
-                    acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0[t], 0, 0, 0);
-                    acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1[t], 0, 0, 0);
-                }
-            }
-            // acc[i]: frame 4 (lane >> 4) + i, column 16 ct + (lane & 15); even column = Re, odd = Im
-            const int col = 16 * ct + (lane & 15);
-            const int bin = col >> 1;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float c = acc0[t][i] + acc1[t][i];
-                    float v = c * c;
-                    v += quad_swap1(v);
-                    if (!(lane & 1) && bin < a.n_bins)
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = acc_re[t][i] * acc_re[t][i] + acc_im[t][i] * acc_im[t][i];
                         P[(t * 16 + 4 * (lane >> 4) + i) * a.ldp + bin] = apply_power<PW>(v, a.pw_mode, a.half_power);
+                    }
                 }
             }
         }

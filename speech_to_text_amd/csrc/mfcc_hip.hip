@@ -1054,14 +1054,16 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) try {
     }
     std::vector<float> dfrag;
     if (!p->fast2048 && !p->small_fft) {
-        // Dense DFT matrix [n_fft x 2 n_bins], columns interleaved (cos, -sin), in the B-fragment
-        // order of v_mfma_f32_16x16x4_f32: lane l supplies B[k = l >> 4][j = l & 15].
-        const int N = r.c.n_fft;
-        p->g_kpad = (N + 15) / 16 * 16;
+        // Dense DFT matrices of the folded transform (front_generic.h): cos(2 pi m k / N) for the sums
+        // p[m] = x[m] + x[N-m] and -sin(2 pi m k / N) for the differences q[m], m = 0 .. N/2, each
+        // [(N/2 + 1) x n_bins] in the B-fragment order of v_mfma_f32_16x16x4_f32: lane l supplies
+        // B[k = l >> 4][j = l & 15].
+        const int N = r.c.n_fft, K2 = N / 2 + 1;
+        p->g_kpad = (K2 + 15) / 16 * 16;
         p->g_lda = 4 * ((p->g_kpad / 16) | 1);      // an odd number of 16-byte quads per row
         p->g_ldp = (std::max(r.n_bins, p->sm.max_read + 1) + 3) / 4 * 4;
-        p->g_coltiles = (2 * r.n_bins + 15) / 16;
-        const size_t per_tile = sizeof(float) * (64 * (size_t)p->g_lda + 16 * (size_t)p->g_ldp);
+        p->g_coltiles = (r.n_bins + 15) / 16;
+        const size_t per_tile = sizeof(float) * (128 * (size_t)p->g_lda + 16 * (size_t)p->g_ldp);
         p->g_nt = (int)std::min<size_t>(4, (size_t)k2048::LDS_LIMIT / per_tile);   // tiles per workgroup pass
         if (const char* e = getenv("MFCC_HIP_GENERIC_NT")) p->g_nt = std::min(p->g_nt, std::max(1, atoi(e)));
         p->g_lds_bytes = per_tile * std::max(1, p->g_nt);
@@ -1070,18 +1072,20 @@ int mfcc_plan_create(const mfcc_config* cfg, mfcc_plan** out_plan) try {
             return fail(MFCC_E_UNSUPPORTED, "n_fft too large for the generic (dense DFT) kernel; "
                                             "supported: n_fft = 2048, or even n_fft up to about 1600");
         }
-        const int ksteps = p->g_kpad / 4;
-        dfrag.assign((size_t)p->g_coltiles * ksteps * 64, 0.0f);
+        const int ks4 = p->g_kpad / 16;
+        dfrag.assign((size_t)p->g_coltiles * ks4 * 2 * 64 * 4, 0.0f);
         for (int ct = 0; ct < p->g_coltiles; ++ct)
-            for (int s = 0; s < ksteps; ++s)
-                for (int l = 0; l < 64; ++l) {
-                    const int n = 4 * s + (l >> 4), col = 16 * ct + (l & 15), bin = col >> 1;
-                    if (n >= N || bin >= r.n_bins) continue;
-                    const double ang = 2.0 * PI * (double)(((int64_t)n * bin) % N) / (double)N;
-                    // four consecutive steps of a lane are adjacent: one 16-byte load
-                    dfrag[(((size_t)ct * (ksteps / 4) + s / 4) * 64 + l) * 4 + (s & 3)] =
-                        (float)((col & 1) ? -std::sin(ang) : std::cos(ang));
-                }
+            for (int s4 = 0; s4 < ks4; ++s4)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 4; ++j) {
+                        // four consecutive steps of a lane are adjacent: one 16-byte load
+                        const int m = 16 * s4 + 4 * j + (l >> 4), bin = 16 * ct + (l & 15);
+                        if (m >= K2 || bin >= r.n_bins) continue;
+                        const double ang = 2.0 * PI * (double)(((int64_t)m * bin) % N) / (double)N;
+                        const size_t at = ((((size_t)ct * ks4 + s4) * 2) * 64 + l) * 4 + j;
+                        dfrag[at] = (float)std::cos(ang);
+                        if (m > 0 && m < N / 2) dfrag[at + 64 * 4] = (float)-std::sin(ang);
+                    }
     }
     std::vector<MelPass> passes(p->sm.n_pass);
     for (int i = 0; i < p->sm.n_pass; ++i) passes[i] = MelPass{p->sm.rounds[i], p->sm.round_off[i]};
