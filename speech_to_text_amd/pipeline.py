@@ -48,15 +48,19 @@ class _Computed:
 class FeatureStream:
     """``config``: the MFCC configuration; ``try_int16``: float waveforms that lie on the int16 grid
     are converted to 16-bit PCM while they are packed (half the upload, bit-identical features);
+    with ``"auto"`` that is tried until a batch turns out to be off the grid (its first chunk
+    tells) and not again afterwards;
     ``check_finite``: librosa's ``valid_audio`` finiteness check, run on the device;
     ``slots``: pinned host buffers for finished batches (one being filled, one being written,
     one spare)."""
 
-    def __init__(self, config: MfccConfig, device=None, *, try_int16: bool = False, check_finite: bool = True,
+    def __init__(self, config: MfccConfig, device=None, *, try_int16=False, check_finite: bool = True,
                  slots: int = 3):
         self.plan = get_plan(config, device)
         self.config = config
         self.device = self.plan.device
+        self.auto_int16 = try_int16 == "auto"
+        self.uploads = {"i16": 0, "f32": 0}      # batches uploaded as 16-bit PCM / as float32
         self.try_int16 = bool(try_int16)
         self.check_finite = bool(check_finite)
         self._free: "queue.Queue" = queue.Queue()
@@ -77,7 +81,10 @@ class FeatureStream:
                     raise ParameterError("Audio data must be floating-point")
             chans = [c if c.dtype == np.float32 else c.astype(np.float32) for c in chans]
         mode = "i16" if pcm16 else ("f32_to_i16" if self.try_int16 else "f32")
-        pcm, _kind, ev = staging.upload_ragged(chans, so, self.device, mode, join=False)
+        pcm, kind, ev = staging.upload_ragged(chans, so, self.device, mode, join=False)
+        if mode == "f32_to_i16" and kind != "i16" and self.auto_int16:
+            self.try_int16 = False           # this source is not 16-bit audio: stop trying
+        self.uploads[kind] += 1
         return _Staged(pcm, so, ev, lens)
 
     # -- compute: the thread that owns the compute stream ---------------------------------------
@@ -128,18 +135,19 @@ class FeatureStream:
             comp.slot = None
 
 
-def features_of_batches(batches, config: MfccConfig, device=None, *, try_int16: bool = False,
+def features_of_batches(batches, config: MfccConfig, device=None, *, try_int16=False,
                         check_finite: bool = True, ahead: int = 2, timeline: Optional[dict] = None):
     """Generator over ``(tag, features (total_frames, n_mfcc), frame_offsets, release)`` for an iterable
     of ``(tag, waves)``: a staging thread packs and uploads up to ``ahead`` batches in advance, the
     calling thread computes batch k + 1 before it hands out batch k.  ``features`` lives in a
     pinned slot until ``release()`` is called (from any thread).  ``timeline``: a dict that receives
-    the (start, end) wall-clock pairs of every stage / compute / fetch call."""
+    the (start, end) wall-clock pairs of every stage / compute / fetch call and, under 'uploads', how many
+    batches went to the device as 16-bit PCM and how many as float32."""
     import time
 
     fs = FeatureStream(config, device, try_int16=try_int16, check_finite=check_finite, slots=ahead + 2)
     if timeline is not None:
-        timeline.update({"stage": [], "compute": [], "fetch": []})
+        timeline.update({"stage": [], "compute": [], "fetch": [], "uploads": fs.uploads})
     staged: "queue.Queue" = queue.Queue(maxsize=max(1, int(ahead)))
     stop = threading.Event()
     _END = object()

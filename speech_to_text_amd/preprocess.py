@@ -107,7 +107,9 @@ class Preprocessor:
     - out_dir: where the per-utterance files go ('mfcc', relative to the CWD, in the reference)
     - rank / world_size: this process's shard of the utterances (one process per GPU)
     - ingest: 'float32' uploads the waveforms as they are; 'int16' uploads 16-bit PCM whenever
-      every waveform of a batch lies on the int16 grid (bit-identical features, half the upload)
+      every waveform of a batch lies on the int16 grid (bit-identical features, half the upload:
+      what torchaudio yields for the 16-bit FLAC of /root/reference/src/preprocess.py:75 does);
+      'auto' (the default) does that until a batch is found off the grid, then stops trying
     - lengths: optional manifest, samples per item (from file sizes or a metadata table): the
       ranks' shards are then balanced by frame count; without it items are dealt round-robin.
       Either way no audio is decoded to decide who takes what.
@@ -120,7 +122,7 @@ class Preprocessor:
 
     def __init__(self, data: Optional[Iterable[Item]] = None, out_dir: str = "mfcc", *, device=None,
                  rank: int = 0, world_size: int = 1, max_batch_seconds: float = 1800.0,
-                 hdf5_backend: Optional[str] = None, extractor=None, ingest: str = "float32",
+                 hdf5_backend: Optional[str] = None, extractor=None, ingest: str = "auto",
                  lengths: Optional[Sequence[int]] = None, decode_workers: Optional[int] = None):
         # MFCC meta parameters, as /root/reference/src/preprocess.py:60-62
         self.hop_length = 512
@@ -133,8 +135,8 @@ class Preprocessor:
         self.max_batch_seconds = float(max_batch_seconds)
         self.hdf5_backend = hdf5_backend
         self._extract = extractor          # injectable for host-only tests
-        if ingest not in ("float32", "int16"):
-            raise ValueError("ingest must be 'float32' or 'int16'")
+        if ingest not in ("auto", "float32", "int16"):
+            raise ValueError("ingest must be 'auto', 'float32' or 'int16'")
         self.ingest = ingest
         self.lengths = lengths
         self.decode_workers = decode_workers
@@ -147,7 +149,7 @@ class Preprocessor:
         from .feature import mfcc_batch
 
         return mfcc_batch(waveforms, n_fft=self.n_fft, hop_length=self.hop_length, n_mfcc=self.n_mfcc,
-                          device=self.device, int16_if_exact=self.ingest == "int16")
+                          device=self.device, int16_if_exact=self.ingest != "float32")
 
     def _write(self, item: Item, frames: np.ndarray) -> None:
         _, sample_rate, transcript, speaker_id, chapter_id, utterance_id = item
@@ -328,7 +330,7 @@ class Preprocessor:
         with ThreadPoolExecutor(max_workers=1) as pool:
             pending = []
             for metas, host, fo, release in features_of_batches(tagged(), cfg, self.device,
-                                                                try_int16=self.ingest == "int16", timeline=timeline):
+                                                                try_int16={"auto": "auto", "int16": True, "float32": False}[self.ingest], timeline=timeline):
                 if packed:
                     block = host.copy()
                     release()
@@ -346,6 +348,7 @@ class Preprocessor:
                 f.result()
         self.stats["file_writer"] = {"threads": write_threads, "seconds_in_writer": t_write[0]}
         # seconds each stage was busy, and the wall clock from the first stage call to the last write
+        self.stats["uploaded_as"] = dict(timeline.pop("uploads", {}))
         spans = [x for v in timeline.values() for x in v]
         self.stats["stage_seconds"] = {k: sum(b - a for a, b in v) for k, v in timeline.items()}
         self.stats["stage_seconds"]["wall"] = (max(b for _, b in spans) - min(a for a, _ in spans)) if spans else 0.0

@@ -533,3 +533,32 @@ def test_preprocess_overlapped_files_match_oracle_and_stats(gpu, tmp_path):
             assert list(attrs) == ["speaker_id", "chapter_id", "utterance_id", "sample_rate", "transcript"]
             if i % 5 == 0:
                 np.testing.assert_allclose(arr, R.process_audio_features(it[0][0]), rtol=0, atol=1e-2)
+
+
+def test_preprocess_ingest_auto_follows_the_data(gpu, tmp_path):
+    """The default ingest: waveforms on the int16 grid (what a 16-bit FLAC decodes to) go up as 16-bit
+    PCM, batch after batch; waveforms off the grid are found out on the first batch and the
+    conversion is not tried again.  Either way the files hold the float32 path's features bit for bit."""
+    import speech_to_text_amd as S
+
+    lens = ragged_lengths(17, 0.4, 2.0, seed=31)
+    for grid in (True, False):
+        items = [(speech_like(int(n), seed=700 + i, int16_grid=grid)[None, :], 16000, f"T{i}", 1, 2, i) for i, n in enumerate(lens)]
+        outs = {}
+        for ingest in ("auto", "float32"):
+            out = tmp_path / f"{ingest}_{grid}"
+            pre = S.Preprocessor(items, str(out), device=gpu, max_batch_seconds=5.0, hdf5_backend="native",
+                                 **({} if ingest == "auto" else {"ingest": ingest}))
+            assert pre.ingest == ingest and pre.preprocess(verbose=False) == len(items)
+            up = pre.stats["uploaded_as"]
+            assert up["i16"] + up["f32"] == pre.stats["batches"] >= 4
+            if ingest == "auto":
+                assert (up["f32"] == 0) if grid else (up["i16"] == 0)
+            else:
+                assert up["i16"] == 0
+            outs[ingest] = out
+        for it in items:
+            name = f"{it[3]}_{it[4]}_{it[5]}.hdf5"
+            a, _ = S.read_feature_file(outs["auto"] / name)
+            b, _ = S.read_feature_file(outs["float32"] / name)
+            assert np.array_equal(a, b)

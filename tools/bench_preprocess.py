@@ -4,8 +4,9 @@ Preprocessor.preprocess (the reference's `--preprocess`, /root/reference/src/pre
 
     python tools/bench_preprocess.py [--hours H] [--out file.json]
 
-Variants: one HDF5 file per utterance as the reference writes them, one packed file per rank, the
-packed file with 16-bit PCM ingest, and the per-utterance files from a LAZY dataset whose
+Variants: one HDF5 file per utterance as the reference writes them, one packed file per rank, both
+with the default ingest (16-bit PCM upload for waveforms on the int16 grid) and with plain float32
+upload, the same from a corpus held as 16-bit PCM, and the per-utterance files from a LAZY dataset whose
 ``__getitem__`` produces the float32 waveform on demand (int16 -> float32, the last step of a
 decode), in batches of 30 minutes of audio, which is how a corpus larger than host memory runs.
 The waveforms are synthetic (LibriSpeech-like lengths, values on the int16 grid); FLAC decode
@@ -143,9 +144,12 @@ def main():
         res["mfcc_batch_int16_host_to_host"] = {"seconds": dt, "audio_hours_per_s": hours / dt,
                                                 "note": "host int16 PCM arrays -> host (F, 13) arrays, no files"}
         del feats, waves16
+        # ingest 'auto' (the default) uploads these waveforms, which lie on the int16 grid as decoded
+        # 16-bit FLAC does, as 16-bit PCM; 'float32' uploads them as they are
         for name, kw, pkw in (("files_per_utterance", {}, dict(multiprocess=True)),
+                              ("files_per_utterance_float32_ingest", dict(ingest="float32"), dict(multiprocess=True)),
                               ("packed_file", {}, dict(multiprocess=True, packed=True)),
-                              ("packed_file_int16_ingest", dict(ingest="int16"), dict(multiprocess=True, packed=True))):
+                              ("packed_file_float32_ingest", dict(ingest="float32"), dict(multiprocess=True, packed=True))):
             out = base / name
             pre = S.Preprocessor(items, str(out), **kw)
             dt, n = timed(lambda: pre.preprocess(verbose=False, **pkw))
